@@ -1,0 +1,356 @@
+"""mapper_amd -- thin Python binding (ctypes) of libgpumap.so, the MI355X-native query hot path
+of ezorita/mapper.  The library is the product; this module only hands numpy buffers to the C-ABI
+declared in include/gpumap.h and never computes results itself.  There is no CPU fallback: if the
+HIP library is missing, importing the compute classes fails loudly.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgpumap.so")
+QUERY_PREFIX, QUERY_SUFFIX = 0, 1
+MAX_TAU = 7
+MAX_READ_LEN = 256
+
+
+def build_library(force=False):
+    """Compile libgpumap.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-s", "-C", os.path.join(_HERE, "csrc")]
+    if force:
+        subprocess.check_call(args + ["clean"])
+    subprocess.check_call(args)
+    return LIB_PATH
+
+
+class IndexView(C.Structure):
+    _fields_ = [
+        ("occ", C.c_void_p), ("occ_length", C.c_int64), ("occ_mark_intv", C.c_int64),
+        ("occ_word_size", C.c_int64), ("c", C.c_void_p),
+        ("sa", C.c_void_p), ("sar_bits", C.c_int64), ("sar_len", C.c_int64),
+        ("txt_len", C.c_int64), ("seq_cnt", C.c_int64), ("seq_len", C.c_void_p), ("seq_beg", C.c_void_p),
+        ("seq_name", C.POINTER(C.c_char_p)), ("wil_cnt", C.c_int64), ("rc_flag", C.c_int64), ("text", C.c_void_p),
+        ("sym_count", C.c_int32), ("sym_table", C.c_void_p), ("com_table", C.c_void_p),
+    ]
+
+
+class DevIndex(C.Structure):
+    _fields_ = [("occ_blocks", C.c_void_p), ("occ_bytes", C.c_int64), ("sa_words", C.c_void_p),
+                ("sa_bytes", C.c_int64), ("tables", C.c_void_p), ("tables_bytes", C.c_int64)]
+
+
+class _Hits(C.Structure):
+    _fields_ = [
+        ("n_reads", C.c_int64), ("status", C.POINTER(C.c_int64)),
+        ("n_locs", C.c_int64), ("read_first_loc", C.POINTER(C.c_int64)), ("loc_read", C.POINTER(C.c_int64)),
+        ("loc_pos", C.POINTER(C.c_int64)), ("loc_fwd", C.POINTER(C.c_int64)), ("loc_seq", C.POINTER(C.c_int64)),
+        ("loc_seqpos", C.POINTER(C.c_int64)), ("loc_strand", C.POINTER(C.c_uint8)), ("loc_score", C.POINTER(C.c_uint8)),
+        ("n_hits", C.c_int64), ("hit_read", C.POINTER(C.c_int64)), ("hit_fp", C.POINTER(C.c_int64)),
+        ("hit_rp", C.POINTER(C.c_int64)), ("hit_sz", C.POINTER(C.c_int64)), ("hit_dp", C.POINTER(C.c_int64)),
+        ("hit_score", C.POINTER(C.c_int64)), ("hit_align", C.POINTER(C.c_uint64)),
+        ("n_ext", C.c_int64), ("ms_search", C.c_float), ("ms_locate", C.c_float), ("ms_sort", C.c_float),
+        ("ms_total", C.c_float),
+    ]
+
+
+# every symbol include/gpumap.h declares: name -> (restype, argtypes)
+_P, _I64, _I = C.c_void_p, C.c_int64, C.c_int
+API = {
+    "gpumap_index_read": (_P, [C.c_char_p]),
+    "gpumap_index_build": (_P, [C.c_char_p, C.c_char_p]),
+    "gpumap_index_free": (None, [_P]),
+    "gpumap_index_view_of": (_I, [_P, C.POINTER(IndexView)]),
+    "gpumap_pos_to_str": (_I, [_P, _I64, C.c_char_p, C.c_size_t]),
+    "gpumap_create": (_P, [C.POINTER(IndexView), _I]),
+    "gpumap_create_from_files": (_P, [C.c_char_p, _I]),
+    "gpumap_destroy": (None, [_P]),
+    "gpumap_devindex_header_size": (C.c_size_t, []),
+    "gpumap_devindex_export": (_I, [_P, C.POINTER(DevIndex), _P]),
+    "gpumap_create_from_device": (_P, [C.POINTER(DevIndex), _P, _I]),
+    "gpumap_occ_all": (_I, [_P, _I64, _P, _P]),
+    "gpumap_query_all": (_I, [_P, _I, _I64, _P, _P, _P, _P]),
+    "gpumap_sar_get": (_I, [_P, _I64, _P, _P]),
+    "gpumap_sar_get_range": (_I, [_P, _I64, _I64, _P]),
+    "gpumap_encode": (_I, [_P, _P, _P, _I64, _P]),
+    "gpumap_map_batch": (_I, [_P, _P, _P, _I64, _I, _I, C.POINTER(_Hits)]),
+    "gpumap_hits_free": (None, [C.POINTER(_Hits)]),
+    "gpumap_batch_upload": (_P, [_P, _P, _P, _I64]),
+    "gpumap_batch_upload_text": (_P, [_P, _P, _P, _I64]),
+    "gpumap_batch_run": (_I, [_P, _P, _I, _I]),
+    "gpumap_batch_fetch": (_I, [_P, _P, C.POINTER(_Hits)]),
+    "gpumap_batch_counters": (_I, [_P, C.POINTER(_I64), C.POINTER(_I64), C.POINTER(_I64), C.POINTER(C.c_float)]),
+    "gpumap_batch_free": (None, [_P]),
+    "gpumap_mapper": (_I, [C.c_char_p, _P, _P, _I, C.c_char_p]),
+    "gpumap_set_option": (_I, [_P, C.c_char_p, _I64]),
+    "gpumap_version": (C.c_char_p, []),
+}
+# host-side extra (not in the reference): index from code arrays, for synthetic genomes
+API_EXTRA = {
+    "gpumap_index_build_codes": (_P, [_P, _P, C.POINTER(C.c_char_p), _I64, C.c_char_p]),
+    "gpumap_suffix_sort": (_I, [_P, _I64, _P]),
+}
+
+_lib = None
+
+
+def lib():
+    """Loads libgpumap.so; raises if it is not built.  No fallback of any kind."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libgpumap.so is not built (%s): run __graft_entry__.build() or make -C mapper_amd/csrc"
+                               % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in list(API.items()) + list(API_EXTRA.items()):
+            f = getattr(L, name)
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None and a.size else None
+
+
+class GpumapError(RuntimeError):
+    pass
+
+
+class HostIndex:
+    """index_t of the reference (src/index.h:19-33): the four mmapped files, or a fresh build."""
+
+    def __init__(self, handle):
+        if not handle:
+            raise GpumapError("index could not be read or built (see stderr)")
+        self._h = handle
+        self.view = IndexView()
+        if lib().gpumap_index_view_of(self._h, C.byref(self.view)) != 0:
+            raise GpumapError("gpumap_index_view_of failed")
+
+    @classmethod
+    def read(cls, base):
+        return cls(lib().gpumap_index_read(os.fsencode(base)))
+
+    @classmethod
+    def build(cls, fasta, base):
+        return cls(lib().gpumap_index_build(os.fsencode(fasta), os.fsencode(base)))
+
+    @classmethod
+    def build_codes(cls, seqs, names, base=None):
+        """seqs: list of uint8 code arrays (0..4)."""
+        codes = np.ascontiguousarray(np.concatenate(seqs) if len(seqs) else np.zeros(0, np.uint8), dtype=np.uint8)
+        lens = np.array([len(s) for s in seqs], dtype=np.int64)
+        arr = (C.c_char_p * len(names))(*[n.encode() for n in names])
+        return cls(lib().gpumap_index_build_codes(_ptr(codes) or 0, _ptr(lens), arr, len(seqs),
+                                                  os.fsencode(base) if base else None))
+
+    @property
+    def txt_len(self):
+        return self.view.txt_len
+
+    def seq_names(self):
+        return [self.view.seq_name[i].decode() for i in range(self.view.seq_cnt)]
+
+    def pos_to_str(self, pos):
+        buf = C.create_string_buffer(1024)
+        n = lib().gpumap_pos_to_str(self._h, pos, buf, 1024)
+        if n < 0:
+            raise GpumapError("position out of bounds")
+        return buf.value.decode()
+
+    def close(self):
+        if self._h:
+            lib().gpumap_index_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Hits:
+    """Result of one batch as numpy arrays (copied out of the library's malloc'ed buffers)."""
+
+    def __init__(self, raw):
+        def arr(p, n, dt):
+            return np.ctypeslib.as_array(p, shape=(max(n, 1),))[:n].astype(dt, copy=True) if n > 0 else np.zeros(0, dt)
+        R, L, H = raw.n_reads, raw.n_locs, raw.n_hits
+        self.n_reads, self.n_locs, self.n_hits, self.n_ext = R, L, H, raw.n_ext
+        self.status = arr(raw.status, R, np.int64)
+        self.read_first_loc = arr(raw.read_first_loc, R + 1, np.int64)
+        for k in ("loc_read", "loc_pos", "loc_fwd", "loc_seq", "loc_seqpos"):
+            setattr(self, k, arr(getattr(raw, k), L, np.int64))
+        self.loc_strand = arr(raw.loc_strand, L, np.uint8)
+        self.loc_score = arr(raw.loc_score, L, np.uint8)
+        if raw.hit_read:
+            for k in ("hit_read", "hit_fp", "hit_rp", "hit_sz", "hit_dp", "hit_score"):
+                setattr(self, k, arr(getattr(raw, k), H, np.int64))
+            self.hit_align = arr(raw.hit_align, 4 * H, np.uint64).reshape(-1, 4)
+        self.ms = dict(search=raw.ms_search, locate=raw.ms_locate, sort=raw.ms_sort, total=raw.ms_total)
+
+    def located(self):
+        """int64 [n_locs][3] = (read, text_pos, score): reads in input order, positions ascending."""
+        return np.stack([self.loc_read, self.loc_pos, self.loc_score.astype(np.int64)], axis=1) if self.n_locs else \
+            np.zeros((0, 3), np.int64)
+
+    def intervals(self):
+        """int64 [n_hits][10] = read, fp, rp, sz, dp, score, align0..3, sorted by (read, fp)."""
+        if self.n_hits == 0:
+            return np.zeros((0, 10), np.int64)
+        return np.concatenate([np.stack([self.hit_read, self.hit_fp, self.hit_rp, self.hit_sz, self.hit_dp,
+                                         self.hit_score], axis=1), self.hit_align.view(np.int64)], axis=1)
+
+
+class Batch:
+    def __init__(self, ctx, handle, n_reads):
+        if not handle:
+            raise GpumapError("batch upload failed (see stderr)")
+        self.ctx, self._h, self.n_reads = ctx, handle, n_reads
+
+    def run(self, tau, want_intervals=False):
+        if lib().gpumap_batch_run(self.ctx._h, self._h, tau, int(want_intervals)) != 0:
+            raise GpumapError("gpumap_batch_run failed (see stderr)")
+        return self.counters()
+
+    def counters(self):
+        nh, nl, ne = C.c_int64(), C.c_int64(), C.c_int64()
+        ms = (C.c_float * 4)()
+        if lib().gpumap_batch_counters(self._h, C.byref(nh), C.byref(nl), C.byref(ne), ms) != 0:
+            raise GpumapError("gpumap_batch_counters failed")
+        return dict(n_hits=nh.value, n_locs=nl.value, n_ext=ne.value, ms_search=ms[0], ms_locate=ms[1],
+                    ms_sort=ms[2], ms_total=ms[3])
+
+    def fetch(self):
+        raw = _Hits()
+        if lib().gpumap_batch_fetch(self.ctx._h, self._h, C.byref(raw)) != 0:
+            raise GpumapError("gpumap_batch_fetch failed (see stderr)")
+        h = Hits(raw)
+        lib().gpumap_hits_free(C.byref(raw))
+        return h
+
+    def close(self):
+        if self._h:
+            lib().gpumap_batch_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Context:
+    """One GPU: device-resident index (gpumap_ctx)."""
+
+    def __init__(self, handle, keep=None):
+        if not handle:
+            raise GpumapError("gpumap context could not be created (see stderr)")
+        self._h = handle
+        self._keep = keep
+
+    @classmethod
+    def from_index(cls, index, device=0):
+        return cls(lib().gpumap_create(C.byref(index.view), device))
+
+    @classmethod
+    def from_files(cls, base, device=0):
+        return cls(lib().gpumap_create_from_files(os.fsencode(base), device))
+
+    @classmethod
+    def from_device(cls, dev, header, device=0, keep=None):
+        hb = np.frombuffer(bytes(header), dtype=np.uint8).copy()
+        return cls(lib().gpumap_create_from_device(C.byref(dev), _ptr(hb), device), keep=keep)
+
+    def export(self):
+        dev = DevIndex()
+        hdr = np.zeros(lib().gpumap_devindex_header_size(), dtype=np.uint8)
+        if lib().gpumap_devindex_export(self._h, C.byref(dev), _ptr(hdr)) != 0:
+            raise GpumapError("gpumap_devindex_export failed")
+        return dev, hdr
+
+    def set_option(self, name, value):
+        if lib().gpumap_set_option(self._h, name.encode(), int(value)) != 0:
+            raise GpumapError("gpumap_set_option(%s) failed" % name)
+
+    # ---- batched operators
+    def occ_all(self, ptr):
+        ptr = np.ascontiguousarray(ptr, dtype=np.int64)
+        out = np.empty((len(ptr), 5), dtype=np.int64)
+        if lib().gpumap_occ_all(self._h, len(ptr), _ptr(ptr), _ptr(out)) != 0:
+            raise GpumapError("gpumap_occ_all failed")
+        return out
+
+    def query_all(self, end, fp, rp, sz):
+        fp, rp, sz = (np.ascontiguousarray(x, dtype=np.int64) for x in (fp, rp, sz))
+        out = np.empty((len(fp), 5, 3), dtype=np.int64)
+        if lib().gpumap_query_all(self._h, end, len(fp), _ptr(fp), _ptr(rp), _ptr(sz), _ptr(out)) != 0:
+            raise GpumapError("gpumap_query_all failed")
+        return out
+
+    def sar_get(self, pos):
+        pos = np.ascontiguousarray(pos, dtype=np.int64)
+        out = np.empty(len(pos), dtype=np.int64)
+        if lib().gpumap_sar_get(self._h, len(pos), _ptr(pos), _ptr(out)) != 0:
+            raise GpumapError("gpumap_sar_get failed")
+        return out
+
+    def sar_get_range(self, beg, size):
+        out = np.empty(max(size, 1), dtype=np.int64)
+        if lib().gpumap_sar_get_range(self._h, beg, size, _ptr(out)) != 0:
+            raise GpumapError("gpumap_sar_get_range failed")
+        return out[:size]
+
+    def encode(self, text, offsets):
+        t = np.frombuffer(text if isinstance(text, bytes) else text.encode(), dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        out = np.zeros(len(t), dtype=np.uint8)
+        if lib().gpumap_encode(self._h, _ptr(t), _ptr(offsets), len(offsets) - 1, _ptr(out)) != 0:
+            raise GpumapError("gpumap_encode failed")
+        return out
+
+    # ---- mapping
+    def upload(self, codes, offsets):
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        return Batch(self, lib().gpumap_batch_upload(self._h, _ptr(codes), _ptr(offsets), len(offsets) - 1),
+                     len(offsets) - 1)
+
+    def upload_text(self, text, offsets):
+        t = np.frombuffer(text if isinstance(text, bytes) else text.encode(), dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        return Batch(self, lib().gpumap_batch_upload_text(self._h, _ptr(t), _ptr(offsets), len(offsets) - 1),
+                     len(offsets) - 1)
+
+    def map_batch(self, codes, offsets, tau, want_intervals=False):
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        raw = _Hits()
+        if lib().gpumap_map_batch(self._h, _ptr(codes), _ptr(offsets), len(offsets) - 1, tau, int(want_intervals),
+                                  C.byref(raw)) != 0:
+            raise GpumapError("gpumap_map_batch failed (see stderr)")
+        h = Hits(raw)
+        lib().gpumap_hits_free(C.byref(raw))
+        return h
+
+    def mapper(self, qfile, index, tau, out_path):
+        """mapper() of src/mapper.c."""
+        rc = lib().gpumap_mapper(os.fsencode(qfile), index._h, self._h, tau, os.fsencode(out_path) if out_path else None)
+        if rc != 0:
+            raise GpumapError("gpumap_mapper failed (see stderr)")
+
+    def close(self):
+        if self._h:
+            lib().gpumap_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,766 @@
+// gm_device.hip -- device context, batches and the C-ABI entry points that launch kernels.
+// Host plumbing only; the kernels are in gm_kernels.hpp and the shared integer logic in gm_core.hpp.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "gm_host.hpp"
+#include "gm_kernels.hpp"
+
+using namespace gm;
+
+#define HIP_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+   std::fprintf(stderr, "%s\t(%s:%d) error: %s: %s\n", __func__, __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+   errno = 1; goto failure_return; } } while (0)
+
+namespace {
+
+struct DevBuf {
+   void *p = nullptr;
+   size_t cap = 0;
+   hipError_t ensure(size_t bytes)
+   {
+      if (bytes <= cap) return hipSuccess;
+      if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+      size_t want = bytes + bytes / 4 + 256;
+      hipError_t e = hipMalloc(&p, want);
+      if (e != hipSuccess) { e = hipMalloc(&p, bytes); want = bytes; }
+      if (e == hipSuccess) cap = want;
+      return e;
+   }
+   void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+   template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct DevIndexHeader {          // host blob that travels with an exported device index
+   uint64_t magic;
+   int64_t  n, n_blocks, n_super, sar_bits, sar_len, seq_cnt, tables_words;
+   uint8_t  sym_table[256];
+   uint8_t  com_table[8];
+};
+constexpr uint64_t DEVINDEX_MAGIC = 0x47504d4158444e49ULL;
+
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace
+
+struct gpumap_ctx {
+   int device = 0;
+   hipStream_t stream = nullptr;
+   bool owns_index = true;
+   IndexDev ix{};
+   void *d_occ = nullptr, *d_tables = nullptr, *d_sa = nullptr;
+   int64_t occ_bytes = 0, tables_bytes = 0, sa_bytes = 0;
+   int64_t sar_len = 0, tables_words = 0;
+   uint8_t sym_table[256];
+   uint8_t com_table[8];
+   uint8_t *d_sym_table = nullptr;
+   // launch shape
+   int cu_count = 256;
+   int waves_per_cu = 8;
+   int64_t spill_cap = 16384;         // nodes per wave
+   // scratch kept across runs
+   DevBuf spill, counters, op_in, op_out, cub_tmp;
+};
+
+struct gpumap_batch {
+   gpumap_ctx *ctx = nullptr;
+   int64_t n_reads = 0;
+   int stride = 0;
+   std::vector<int64_t> offsets;     // host copy (n_reads + 1)
+   DevBuf reads, read_len, len_row, phases, status;
+   DevBuf hits, hit_sizes, hit_off, keys, keys_alt, read_cnt, read_first;
+   DevBuf loc_read, loc_pos, loc_fwd, loc_seq, loc_seqpos, loc_strand, loc_score;
+   DevBuf hkeys, hkeys_alt, hidx, hidx_alt, hit_read, hit_fp, hit_rp, hit_sz, hit_dp, hit_score, hit_align;
+   bool length_seen[MAX_READ + 1];
+   int64_t n_hits = 0, n_locs = 0, n_ext = 0;
+   bool have_intervals = false, ran = false;
+   int tau = 0;
+   float ms[4] = {0, 0, 0, 0};
+   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+   void release()
+   {
+      for (DevBuf *b : {&reads, &read_len, &len_row, &phases, &status, &hits, &hit_sizes, &hit_off, &keys, &keys_alt,
+                        &read_cnt, &read_first, &loc_read, &loc_pos, &loc_fwd, &loc_seq, &loc_seqpos, &loc_strand,
+                        &loc_score, &hkeys, &hkeys_alt, &hidx, &hidx_alt, &hit_read, &hit_fp, &hit_rp, &hit_sz,
+                        &hit_dp, &hit_score, &hit_align})
+         b->release();
+      for (auto &e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+   }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Context
+// ------------------------------------------------------------------------------------------------
+
+static int ctx_common_init(gpumap_ctx *ctx, int device)
+{
+   hipDeviceProp_t prop;
+   HIP_TRY(hipSetDevice(device));
+   HIP_TRY(hipGetDeviceProperties(&prop, device));
+   ctx->device = device;
+   ctx->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+   HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+   HIP_TRY(hipMalloc((void **)&ctx->d_sym_table, 256));
+   HIP_TRY(hipMemcpy(ctx->d_sym_table, ctx->sym_table, 256, hipMemcpyHostToDevice));
+   HIP_TRY(ctx->counters.ensure(64));
+   return 0;
+failure_return:
+   return -1;
+}
+
+extern "C" void gpumap_destroy(gpumap_ctx *ctx)
+{
+   if (!ctx) return;
+   (void)hipSetDevice(ctx->device);
+   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+   if (ctx->owns_index) {
+      if (ctx->d_occ) (void)hipFree(ctx->d_occ);
+      if (ctx->d_tables) (void)hipFree(ctx->d_tables);
+      if (ctx->d_sa) (void)hipFree(ctx->d_sa);
+   }
+   if (ctx->d_sym_table) (void)hipFree(ctx->d_sym_table);
+   for (DevBuf *b : {&ctx->spill, &ctx->counters, &ctx->op_in, &ctx->op_out, &ctx->cub_tmp}) b->release();
+   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+   delete ctx;
+}
+
+extern "C" gpumap_ctx *gpumap_create(const gpumap_index_view *v, int device)
+{
+   gpumap_ctx *ctx = nullptr;
+   void *d_ref = nullptr, *d_c = nullptr, *d_seq = nullptr;
+   int count = 0;
+   GM_FAIL_IF(v == nullptr, "argument 'view' is NULL.");
+   GM_FAIL_IF(v->occ == nullptr || v->c == nullptr || v->sa == nullptr, "index view has NULL arrays.");
+   GM_FAIL_IF(v->sym_count != SYMS, "only the 5-symbol DNA alphabet is supported.");
+   GM_FAIL_IF(v->occ_word_size != 64 || v->occ_mark_intv < 1, "unsupported Occ layout.");
+   GM_FAIL_IF(v->txt_len < 2 || v->txt_len >= ((int64_t)1 << 40), "text length out of range.");
+   GM_FAIL_IF(v->sar_bits < 1 || v->sar_bits > 40, "sar_bits out of range.");
+   GM_FAIL_IF(v->seq_cnt < 1 || v->seq_beg == nullptr, "index view has no sequences.");
+   GM_FAIL_IF(num_supers(v->txt_len) > MAX_SB_LDS, "text too long for the staged superblock table.");
+   {
+      // the Occ array must be exactly as long as bwt_build_opt makes it (src/index_bwt.c:501-507)
+      int64_t mark_bits = v->occ_mark_intv * 64;
+      int64_t n_intv = cdiv(v->txt_len, mark_bits);
+      GM_FAIL_IF(v->occ_length != (n_intv * v->occ_mark_intv + n_intv + 1) * SYMS, "occ_length does not match txt_len.");
+      GM_FAIL_IF(cdiv(v->txt_len * v->sar_bits, 64) > v->sar_len, "sar_len too small for txt_len.");
+   }
+   HIP_TRY(hipGetDeviceCount(&count));
+   GM_FAIL_IF(device < 0 || device >= count, "no such HIP device.");
+   ctx = new gpumap_ctx();
+   memcpy(ctx->sym_table, v->sym_table, 256);
+   memcpy(ctx->com_table, v->com_table, SYMS + 1);
+   GM_FAIL_IF(ctx_common_init(ctx, device) != 0, "cannot initialise the device context.");
+   {
+      IndexDev &ix = ctx->ix;
+      ix.n = v->txt_len;
+      ix.n_blocks = num_blocks(ix.n);
+      ix.n_super = num_supers(ix.n);
+      ix.sar_bits = (int32_t)v->sar_bits;
+      ix.seq_cnt = (int32_t)v->seq_cnt;
+      ctx->sar_len = v->sar_len;
+      ctx->occ_bytes = ix.n_blocks * 64;
+      ctx->sa_bytes = (v->sar_len + 1) * 8;           // one spare word: an entry read may touch word+1
+      ctx->tables_words = TAB_SBASE + SYMS * ix.n_super + v->seq_cnt;
+      ctx->tables_bytes = ctx->tables_words * 8;
+      HIP_TRY(hipMalloc(&ctx->d_occ, (size_t)ctx->occ_bytes));
+      HIP_TRY(hipMalloc(&ctx->d_tables, (size_t)ctx->tables_bytes));
+      HIP_TRY(hipMalloc(&ctx->d_sa, (size_t)ctx->sa_bytes));
+      HIP_TRY(hipMemset(ctx->d_sa, 0, (size_t)ctx->sa_bytes));
+      HIP_TRY(hipMemcpy(ctx->d_sa, v->sa, (size_t)v->sar_len * 8, hipMemcpyHostToDevice));
+      // K0: upload the reference layout verbatim, repack on the device, drop the copy
+      HIP_TRY(hipMalloc(&d_ref, (size_t)v->occ_length * 8));
+      HIP_TRY(hipMemcpy(d_ref, v->occ, (size_t)v->occ_length * 8, hipMemcpyHostToDevice));
+      HIP_TRY(hipMalloc(&d_c, 8 * (SYMS + 1)));
+      HIP_TRY(hipMemcpy(d_c, v->c, 8 * (SYMS + 1), hipMemcpyHostToDevice));
+      HIP_TRY(hipMemset(ctx->d_tables, 0, (size_t)ctx->tables_bytes));
+      int64_t n_ref_words = cdiv(ix.n, v->occ_mark_intv * 64) * v->occ_mark_intv;
+      int64_t g1 = cdiv(std::max<int64_t>(ix.n_super, SYMS), 64);
+      hipLaunchKernelGGL(k_super_counts, dim3((unsigned)g1), dim3(64), 0, ctx->stream, (const uint64_t *)d_ref,
+                         v->occ_mark_intv, ix.n, ix.n_super, (const uint64_t *)d_c, (uint64_t *)ctx->d_tables);
+      {
+         PackArgs P;
+         P.ref_occ = (const uint64_t *)d_ref; P.tables = (const uint64_t *)ctx->d_tables; P.blocks = (uint32_t *)ctx->d_occ;
+         P.intv = v->occ_mark_intv; P.n_ref_words = n_ref_words; P.n_blocks = ix.n_blocks;
+         hipLaunchKernelGGL(k_pack_blocks, dim3((unsigned)cdiv(ix.n_blocks, 256)), dim3(256), 0, ctx->stream, P);
+      }
+      HIP_TRY(hipGetLastError());
+      // seq_beg sits behind the superblock table
+      HIP_TRY(hipMemcpyAsync((uint64_t *)ctx->d_tables + TAB_SBASE + SYMS * ix.n_super, v->seq_beg,
+                             8 * (size_t)v->seq_cnt, hipMemcpyHostToDevice, ctx->stream));
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      HIP_TRY(hipFree(d_ref)); d_ref = nullptr;
+      HIP_TRY(hipFree(d_c)); d_c = nullptr;
+      ix.occ = (const uint32_t *)ctx->d_occ;
+      ix.tables = (const uint64_t *)ctx->d_tables;
+      ix.sa = (const uint64_t *)ctx->d_sa;
+      ix.seq_beg = (const int64_t *)((const uint64_t *)ctx->d_tables + TAB_SBASE + SYMS * ix.n_super);
+   }
+   (void)d_seq;
+   return ctx;
+failure_return:
+   if (d_ref) (void)hipFree(d_ref);
+   if (d_c) (void)hipFree(d_c);
+   gpumap_destroy(ctx);
+   return nullptr;
+}
+
+extern "C" gpumap_ctx *gpumap_create_from_files(const char *filename_base, int device)
+{
+   gpumap_index *ix = gpumap_index_read(filename_base);
+   if (!ix) return nullptr;
+   gpumap_index_view v;
+   gpumap_index_view_of(ix, &v);
+   gpumap_ctx *ctx = gpumap_create(&v, device);
+   gpumap_index_free(ix);
+   return ctx;
+}
+
+extern "C" size_t gpumap_devindex_header_size(void) { return sizeof(DevIndexHeader); }
+
+extern "C" int gpumap_devindex_export(const gpumap_ctx *ctx, gpumap_devindex *out, void *header)
+{
+   GM_FAIL_IF(ctx == nullptr || out == nullptr || header == nullptr, "NULL argument.");
+   {
+      out->occ_blocks = ctx->d_occ; out->occ_bytes = ctx->occ_bytes;
+      out->sa_words = ctx->d_sa; out->sa_bytes = ctx->sa_bytes;
+      out->tables = ctx->d_tables; out->tables_bytes = ctx->tables_bytes;
+      DevIndexHeader h;
+      memset(&h, 0, sizeof h);
+      h.magic = DEVINDEX_MAGIC;
+      h.n = ctx->ix.n; h.n_blocks = ctx->ix.n_blocks; h.n_super = ctx->ix.n_super;
+      h.sar_bits = ctx->ix.sar_bits; h.sar_len = ctx->sar_len; h.seq_cnt = ctx->ix.seq_cnt;
+      h.tables_words = ctx->tables_words;
+      memcpy(h.sym_table, ctx->sym_table, 256);
+      memcpy(h.com_table, ctx->com_table, 8);
+      memcpy(header, &h, sizeof h);
+   }
+   return 0;
+failure_return:
+   return -1;
+}
+
+extern "C" gpumap_ctx *gpumap_create_from_device(const gpumap_devindex *dev, const void *header, int device)
+{
+   gpumap_ctx *ctx = nullptr;
+   DevIndexHeader h;
+   int count = 0;
+   GM_FAIL_IF(dev == nullptr || header == nullptr, "NULL argument.");
+   memcpy(&h, header, sizeof h);
+   GM_FAIL_IF(h.magic != DEVINDEX_MAGIC, "bad device index header.");
+   GM_FAIL_IF(h.n < 2 || h.n_blocks != num_blocks(h.n) || h.n_super != num_supers(h.n), "inconsistent device index header.");
+   GM_FAIL_IF(dev->occ_bytes < h.n_blocks * 64 || dev->sa_bytes < (h.sar_len + 1) * 8 ||
+              dev->tables_bytes < h.tables_words * 8, "device index buffers are too small.");
+   GM_FAIL_IF(dev->occ_blocks == nullptr || dev->sa_words == nullptr || dev->tables == nullptr, "NULL device buffer.");
+   HIP_TRY(hipGetDeviceCount(&count));
+   GM_FAIL_IF(device < 0 || device >= count, "no such HIP device.");
+   ctx = new gpumap_ctx();
+   ctx->owns_index = false;
+   memcpy(ctx->sym_table, h.sym_table, 256);
+   memcpy(ctx->com_table, h.com_table, 8);
+   GM_FAIL_IF(ctx_common_init(ctx, device) != 0, "cannot initialise the device context.");
+   ctx->d_occ = dev->occ_blocks; ctx->d_sa = dev->sa_words; ctx->d_tables = dev->tables;
+   ctx->occ_bytes = dev->occ_bytes; ctx->sa_bytes = dev->sa_bytes; ctx->tables_bytes = dev->tables_bytes;
+   ctx->sar_len = h.sar_len; ctx->tables_words = h.tables_words;
+   ctx->ix.n = h.n; ctx->ix.n_blocks = h.n_blocks; ctx->ix.n_super = h.n_super;
+   ctx->ix.sar_bits = (int32_t)h.sar_bits; ctx->ix.seq_cnt = (int32_t)h.seq_cnt;
+   ctx->ix.occ = (const uint32_t *)ctx->d_occ;
+   ctx->ix.tables = (const uint64_t *)ctx->d_tables;
+   ctx->ix.sa = (const uint64_t *)ctx->d_sa;
+   ctx->ix.seq_beg = (const int64_t *)((const uint64_t *)ctx->d_tables + TAB_SBASE + SYMS * h.n_super);
+   return ctx;
+failure_return:
+   gpumap_destroy(ctx);
+   return nullptr;
+}
+
+extern "C" int gpumap_set_option(gpumap_ctx *ctx, const char *name, int64_t value)
+{
+   GM_FAIL_IF(ctx == nullptr || name == nullptr, "NULL argument.");
+   if (!strcmp(name, "waves_per_cu")) { GM_FAIL_IF(value < 0 || value > 32, "waves_per_cu out of range."); ctx->waves_per_cu = value ? (int)value : 8; }
+   else if (!strcmp(name, "spill_nodes")) { GM_FAIL_IF(value < 0 || value > (1 << 22), "spill_nodes out of range."); ctx->spill_cap = value ? ((value + SPILL_CHUNK - 1) / SPILL_CHUNK) * SPILL_CHUNK : 16384; }
+   else GM_FAIL("unknown option.");
+   return 0;
+failure_return:
+   return -1;
+}
+
+extern "C" const char *gpumap_version(void) { return "gpumap 0.1 (gfx950)"; }
+
+// ------------------------------------------------------------------------------------------------
+// Batched operators
+// ------------------------------------------------------------------------------------------------
+
+extern "C" int gpumap_occ_all(gpumap_ctx *ctx, int64_t n, const int64_t *ptr, int64_t *occ)
+{
+   GM_FAIL_IF(ctx == nullptr, "argument 'ctx' is NULL.");
+   GM_FAIL_IF(n < 0 || (n > 0 && (ptr == nullptr || occ == nullptr)), "invalid arguments.");
+   if (n == 0) return 0;
+   HIP_TRY(hipSetDevice(ctx->device));
+   HIP_TRY(ctx->op_in.ensure(8 * (size_t)n));
+   HIP_TRY(ctx->op_out.ensure(8 * SYMS * (size_t)n));
+   HIP_TRY(hipMemcpyAsync(ctx->op_in.p, ptr, 8 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+   hipLaunchKernelGGL(k_occ_all, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, ctx->stream, ctx->ix, n,
+                      ctx->op_in.as<const int64_t>(), ctx->op_out.as<int64_t>());
+   HIP_TRY(hipGetLastError());
+   HIP_TRY(hipMemcpyAsync(occ, ctx->op_out.p, 8 * SYMS * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+   HIP_TRY(hipStreamSynchronize(ctx->stream));
+   return 0;
+failure_return:
+   return -1;
+}
+
+extern "C" int gpumap_query_all(gpumap_ctx *ctx, int end, int64_t n, const int64_t *fp, const int64_t *rp,
+                                const int64_t *sz, int64_t *out)
+{
+   GM_FAIL_IF(ctx == nullptr, "argument 'ctx' is NULL.");
+   GM_FAIL_IF(end != GPUMAP_QUERY_SUFFIX && end != GPUMAP_QUERY_PREFIX, "invalid 'end' flag.");
+   GM_FAIL_IF(n < 0 || (n > 0 && (!fp || !rp || !sz || !out)), "invalid arguments.");
+   if (n == 0) return 0;
+   HIP_TRY(hipSetDevice(ctx->device));
+   HIP_TRY(ctx->op_in.ensure(24 * (size_t)n));
+   HIP_TRY(ctx->op_out.ensure(120 * (size_t)n));
+   {
+      int64_t *d = ctx->op_in.as<int64_t>();
+      HIP_TRY(hipMemcpyAsync(d, fp, 8 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+      HIP_TRY(hipMemcpyAsync(d + n, rp, 8 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+      HIP_TRY(hipMemcpyAsync(d + 2 * n, sz, 8 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+      hipLaunchKernelGGL(k_query_all, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, ctx->stream, ctx->ix, end, n,
+                         (const int64_t *)d, (const int64_t *)(d + n), (const int64_t *)(d + 2 * n), ctx->op_out.as<int64_t>());
+   }
+   HIP_TRY(hipGetLastError());
+   HIP_TRY(hipMemcpyAsync(out, ctx->op_out.p, 120 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+   HIP_TRY(hipStreamSynchronize(ctx->stream));
+   return 0;
+failure_return:
+   return -1;
+}
+
+extern "C" int gpumap_sar_get(gpumap_ctx *ctx, int64_t n, const int64_t *pos, int64_t *out)
+{
+   GM_FAIL_IF(ctx == nullptr, "argument 'ctx' is NULL.");
+   GM_FAIL_IF(n < 0 || (n > 0 && (!pos || !out)), "invalid arguments.");
+   if (n == 0) return 0;
+   HIP_TRY(hipSetDevice(ctx->device));
+   HIP_TRY(ctx->op_in.ensure(8 * (size_t)n));
+   HIP_TRY(ctx->op_out.ensure(8 * (size_t)n));
+   HIP_TRY(hipMemcpyAsync(ctx->op_in.p, pos, 8 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+   hipLaunchKernelGGL(k_sar_get, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, ctx->stream, ctx->ix, n,
+                      ctx->op_in.as<const int64_t>(), ctx->op_out.as<int64_t>());
+   HIP_TRY(hipGetLastError());
+   HIP_TRY(hipMemcpyAsync(out, ctx->op_out.p, 8 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+   HIP_TRY(hipStreamSynchronize(ctx->stream));
+   return 0;
+failure_return:
+   return -1;
+}
+
+extern "C" int gpumap_sar_get_range(gpumap_ctx *ctx, int64_t beg, int64_t size, int64_t *vec)
+{
+   GM_FAIL_IF(ctx == nullptr, "argument 'ctx' is NULL.");
+   GM_FAIL_IF(vec == nullptr, "argument 'vec' is NULL.");
+   GM_FAIL_IF(beg < 0, "'beg' index must be positive.");
+   GM_FAIL_IF(size < 1, "'size' must be greater than 0.");
+   GM_FAIL_IF(beg + size > ctx->ix.n, "range out of bounds.");
+   {
+      std::vector<int64_t> pos((size_t)size);
+      for (int64_t i = 0; i < size; i++) pos[i] = beg + i;
+      return gpumap_sar_get(ctx, size, pos.data(), vec);
+   }
+failure_return:
+   return -1;
+}
+
+extern "C" int gpumap_encode(gpumap_ctx *ctx, const char *text, const int64_t *offsets, int64_t n_reads, uint8_t *codes)
+{
+   GM_FAIL_IF(ctx == nullptr, "argument 'ctx' is NULL.");
+   GM_FAIL_IF(n_reads < 0 || offsets == nullptr, "invalid arguments.");
+   {
+      int64_t total = offsets[n_reads] - offsets[0];
+      if (total <= 0) return 0;
+      GM_FAIL_IF(text == nullptr || codes == nullptr, "argument 'str' is NULL.");
+      HIP_TRY(hipSetDevice(ctx->device));
+      HIP_TRY(ctx->op_in.ensure((size_t)total));
+      HIP_TRY(ctx->op_out.ensure((size_t)total));
+      HIP_TRY(hipMemcpyAsync(ctx->op_in.p, text + offsets[0], (size_t)total, hipMemcpyHostToDevice, ctx->stream));
+      hipLaunchKernelGGL(k_encode_flat, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, ctx->stream,
+                         ctx->op_in.as<const uint8_t>(), total, (const uint8_t *)ctx->d_sym_table, ctx->op_out.as<uint8_t>());
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipMemcpyAsync(codes + offsets[0], ctx->op_out.p, (size_t)total, hipMemcpyDeviceToHost, ctx->stream));
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+   }
+   return 0;
+failure_return:
+   return -1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Batches
+// ------------------------------------------------------------------------------------------------
+
+extern "C" void gpumap_batch_free(gpumap_batch *b)
+{
+   if (!b) return;
+   if (b->ctx) (void)hipSetDevice(b->ctx->device);
+   b->release();
+   delete b;
+}
+
+static gpumap_batch *batch_upload(gpumap_ctx *ctx, const uint8_t *src, const int64_t *offsets, int64_t n_reads, bool is_text)
+{
+   gpumap_batch *b = nullptr;
+   DevBuf d_src, d_off;
+   GM_FAIL_IF(ctx == nullptr, "argument 'ctx' is NULL.");
+   GM_FAIL_IF(n_reads < 0 || offsets == nullptr, "invalid arguments.");
+   GM_FAIL_IF(n_reads >= ((int64_t)1 << 31), "too many reads in one batch.");
+   HIP_TRY(hipSetDevice(ctx->device));
+   b = new gpumap_batch();
+   b->ctx = ctx;
+   b->n_reads = n_reads;
+   b->offsets.assign(offsets, offsets + n_reads + 1);
+   memset(b->length_seen, 0, sizeof b->length_seen);
+   {
+      int64_t maxlen = 1;
+      for (int64_t r = 0; r < n_reads; r++) {
+         int64_t len = offsets[r + 1] - offsets[r];
+         GM_FAIL_IF(len < 0, "offsets must not decrease.");
+         if (len <= MAX_READ) { b->length_seen[len] = true; maxlen = std::max(maxlen, len); }
+      }
+      b->stride = (int)((maxlen + 3) & ~(int64_t)3);
+      int64_t total = offsets[n_reads] - offsets[0];
+      GM_FAIL_IF(total > 0 && src == nullptr, "argument 'codes' is NULL.");
+      HIP_TRY(b->reads.ensure((size_t)std::max<int64_t>(1, n_reads) * b->stride));
+      HIP_TRY(b->read_len.ensure(2 * (size_t)std::max<int64_t>(1, n_reads)));
+      HIP_TRY(b->status.ensure(8 * (size_t)std::max<int64_t>(1, n_reads)));
+      for (auto &e : b->ev) HIP_TRY(hipEventCreate(&e));
+      if (n_reads > 0) {
+         HIP_TRY(d_src.ensure((size_t)std::max<int64_t>(1, total)));
+         HIP_TRY(d_off.ensure(8 * (size_t)(n_reads + 1)));
+         if (total > 0) HIP_TRY(hipMemcpyAsync(d_src.p, src + offsets[0], (size_t)total, hipMemcpyHostToDevice, ctx->stream));
+         std::vector<int64_t> rel((size_t)n_reads + 1);
+         for (int64_t r = 0; r <= n_reads; r++) rel[r] = offsets[r] - offsets[0];
+         HIP_TRY(hipMemcpyAsync(d_off.p, rel.data(), 8 * (size_t)(n_reads + 1), hipMemcpyHostToDevice, ctx->stream));
+         int64_t threads = n_reads * b->stride;
+         hipLaunchKernelGGL(k_encode, dim3((unsigned)cdiv(threads, 256)), dim3(256), 0, ctx->stream,
+                            d_src.as<const uint8_t>(), d_off.as<const int64_t>(), n_reads, b->stride,
+                            is_text ? (const uint8_t *)ctx->d_sym_table : (const uint8_t *)nullptr,
+                            b->reads.as<uint8_t>(), b->read_len.as<uint16_t>(), (uint8_t *)nullptr);
+         HIP_TRY(hipGetLastError());
+         HIP_TRY(hipStreamSynchronize(ctx->stream));
+      }
+   }
+   d_src.release(); d_off.release();
+   return b;
+failure_return:
+   d_src.release(); d_off.release();
+   gpumap_batch_free(b);
+   return nullptr;
+}
+
+extern "C" gpumap_batch *gpumap_batch_upload(gpumap_ctx *ctx, const uint8_t *codes, const int64_t *offsets, int64_t n_reads)
+{
+   return batch_upload(ctx, codes, offsets, n_reads, false);
+}
+
+extern "C" gpumap_batch *gpumap_batch_upload_text(gpumap_ctx *ctx, const char *text, const int64_t *offsets, int64_t n_reads)
+{
+   return batch_upload(ctx, (const uint8_t *)text, offsets, n_reads, true);
+}
+
+static int bits_for(uint64_t v) { int b = 0; while (b < 64 && (v >> b)) b++; return b; }
+
+extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals)
+{
+   GM_FAIL_IF(ctx == nullptr || b == nullptr, "NULL argument.");
+   GM_FAIL_IF(b->ctx != ctx, "batch belongs to another context.");
+   GM_FAIL_IF(tau < 0, "argument 'tau' must be positive.");
+   GM_FAIL_IF(tau > MAX_TAU, "argument 'tau' exceeds GPUMAP_MAX_TAU.");
+   HIP_TRY(hipSetDevice(ctx->device));
+   {
+      hipStream_t st = ctx->stream;
+      const int64_t R = b->n_reads;
+      b->tau = tau; b->ran = false; b->n_hits = b->n_locs = b->n_ext = 0; b->have_intervals = false;
+      // ---- schedule: one phase-table row per read length present (src/blocksearch.c:138-170)
+      std::vector<uint8_t> len_row(MAX_READ + 1, 0xff);
+      std::vector<uint32_t> phases;
+      int rows = 0;
+      for (int m = 1; m <= MAX_READ; m++) {
+         if (!b->length_seen[m]) continue;
+         uint32_t tab[MAX_PHASES];
+         memset(tab, 0, sizeof tab);
+         if (!build_phase_table(m, tau, tab)) continue;        // the reference returns -1 for this length
+         GM_FAIL_IF(rows >= 255, "too many distinct read lengths.");
+         len_row[m] = (uint8_t)rows++;
+         phases.insert(phases.end(), tab, tab + MAX_PHASES);
+      }
+      if (phases.empty()) phases.assign(MAX_PHASES, 0);
+      HIP_TRY(b->len_row.ensure(MAX_READ + 1));
+      HIP_TRY(b->phases.ensure(4 * phases.size()));
+      HIP_TRY(hipMemcpyAsync(b->len_row.p, len_row.data(), MAX_READ + 1, hipMemcpyHostToDevice, st));
+      HIP_TRY(hipMemcpyAsync(b->phases.p, phases.data(), 4 * phases.size(), hipMemcpyHostToDevice, st));
+      if (R > 0) {
+         hipLaunchKernelGGL(k_status, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, st, b->read_len.as<const uint16_t>(),
+                            b->len_row.as<const uint8_t>(), R, b->status.as<int64_t>());
+         HIP_TRY(hipGetLastError());
+      }
+      HIP_TRY(hipStreamSynchronize(st));          // the staging vectors above go out of scope
+
+      // ---- K2 search (rerun once with an exact buffer if the hit list overflowed)
+      const int n_wg = std::max(1, ctx->cu_count * ctx->waves_per_cu / WG_WAVES);
+      const int64_t n_waves = (int64_t)n_wg * WG_WAVES;
+      HIP_TRY(ctx->spill.ensure((size_t)n_waves * (size_t)ctx->spill_cap * sizeof(Node)));
+      unsigned long long *cnt = ctx->counters.as<unsigned long long>();   // [0] cursor [1] hits [2] n_ext [3] error
+      unsigned long long host_cnt[4] = {0, 0, 0, 0};
+      size_t hit_cap = std::max<size_t>((size_t)1 << 16, (size_t)R * 2);
+      HIP_TRY(hipEventRecord(b->ev[0], st));
+      for (int attempt = 0; attempt < 2; attempt++) {
+         HIP_TRY(b->hits.ensure(hit_cap * sizeof(Node)));
+         hit_cap = b->hits.cap / sizeof(Node);
+         HIP_TRY(hipMemsetAsync(cnt, 0, 64, st));
+         SearchArgs A;
+         A.ix = ctx->ix;
+         A.reads = b->reads.as<const uint8_t>(); A.read_len = b->read_len.as<const uint16_t>();
+         A.len_row = b->len_row.as<const uint8_t>(); A.phases = b->phases.as<const uint32_t>();
+         A.n_reads = R; A.stride = b->stride; A.tau = tau;
+         A.cursor = cnt + 0; A.hits = b->hits.as<Node>(); A.hit_cap = hit_cap; A.hit_count = cnt + 1; A.n_ext = cnt + 2;
+         A.spill = ctx->spill.as<Node>(); A.spill_cap = (uint32_t)ctx->spill_cap; A.error = (int *)(cnt + 3);
+         if (R > 0) {
+            hipLaunchKernelGGL(k_search, dim3((unsigned)n_wg), dim3(WG_THREADS), 0, st, A);
+            HIP_TRY(hipGetLastError());
+         }
+         HIP_TRY(hipMemcpyAsync(host_cnt, cnt, 32, hipMemcpyDeviceToHost, st));
+         HIP_TRY(hipStreamSynchronize(st));
+         GM_FAIL_IF(host_cnt[3] != 0, "search spill region overflowed (raise 'spill_nodes').");
+         if (host_cnt[1] <= hit_cap) break;
+         GM_FAIL_IF(attempt == 1, "hit list overflowed twice.");
+         hit_cap = (size_t)host_cnt[1];
+      }
+      HIP_TRY(hipEventRecord(b->ev[1], st));
+      b->n_hits = (int64_t)host_cnt[1];
+      b->n_ext = (int64_t)host_cnt[2];
+
+      // ---- K3 locate: sizes -> scan -> flat gather
+      const int64_t H = b->n_hits;
+      int64_t L = 0;
+      HIP_TRY(b->read_cnt.ensure(4 * (size_t)(R + 1)));
+      HIP_TRY(b->read_first.ensure(8 * (size_t)(R + 1)));
+      HIP_TRY(hipMemsetAsync(b->read_cnt.p, 0, 4 * (size_t)(R + 1), st));
+      if (H > 0) {
+         HIP_TRY(b->hit_sizes.ensure(8 * (size_t)(H + 1)));
+         HIP_TRY(b->hit_off.ensure(8 * (size_t)(H + 1)));
+         HIP_TRY(hipMemsetAsync(b->hit_sizes.p, 0, 8 * (size_t)(H + 1), st));
+         hipLaunchKernelGGL(k_hit_sizes, dim3((unsigned)cdiv(H, 256)), dim3(256), 0, st, b->hits.as<const Node>(), H,
+                            b->hit_sizes.as<int64_t>());
+         size_t tmp = 0;
+         HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, b->hit_sizes.as<int64_t>(), b->hit_off.as<int64_t>(), (int)(H + 1), st));
+         HIP_TRY(ctx->cub_tmp.ensure(tmp));
+         HIP_TRY(hipcub::DeviceScan::ExclusiveSum(ctx->cub_tmp.p, tmp, b->hit_sizes.as<int64_t>(), b->hit_off.as<int64_t>(), (int)(H + 1), st));
+         HIP_TRY(hipMemcpyAsync(&L, b->hit_off.as<int64_t>() + H, 8, hipMemcpyDeviceToHost, st));
+         HIP_TRY(hipStreamSynchronize(st));
+      }
+      b->n_locs = L;
+      const int pos_bits = ctx->ix.sar_bits;
+      const int read_bits = bits_for((uint64_t)std::max<int64_t>(R, 1));
+      GM_FAIL_IF(pos_bits + 4 + read_bits > 64, "batch too large for the 64-bit sort key (split the batch).");
+      if (L > 0) {
+         GM_FAIL_IF(L >= ((int64_t)1 << 31), "too many located hits in one batch (split the batch).");
+         HIP_TRY(b->keys.ensure(8 * (size_t)L));
+         HIP_TRY(b->keys_alt.ensure(8 * (size_t)L));
+         hipLaunchKernelGGL(k_expand_hits, dim3((unsigned)cdiv(L, 256)), dim3(256), 0, st, ctx->ix, b->hits.as<const Node>(), H,
+                            b->hit_off.as<const int64_t>(), L, pos_bits, b->keys.as<unsigned long long>(),
+                            b->read_cnt.as<unsigned int>());
+         HIP_TRY(hipGetLastError());
+      }
+      HIP_TRY(hipEventRecord(b->ev[2], st));
+      // ---- order: reads in input order, text positions ascending inside a read
+      {
+         size_t tmp = 0;
+         HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, b->read_cnt.as<unsigned int>(), b->read_first.as<int64_t>(), (int)(R + 1), st));
+         HIP_TRY(ctx->cub_tmp.ensure(tmp));
+         HIP_TRY(hipcub::DeviceScan::ExclusiveSum(ctx->cub_tmp.p, tmp, b->read_cnt.as<unsigned int>(), b->read_first.as<int64_t>(), (int)(R + 1), st));
+      }
+      if (L > 0) {
+         hipcub::DoubleBuffer<unsigned long long> db(b->keys.as<unsigned long long>(), b->keys_alt.as<unsigned long long>());
+         size_t tmp = 0;
+         HIP_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp, db, (int)L, 0, pos_bits + 4 + read_bits, st));
+         HIP_TRY(ctx->cub_tmp.ensure(tmp));
+         HIP_TRY(hipcub::DeviceRadixSort::SortKeys(ctx->cub_tmp.p, tmp, db, (int)L, 0, pos_bits + 4 + read_bits, st));
+         for (DevBuf *x : {&b->loc_read, &b->loc_pos, &b->loc_fwd, &b->loc_seq, &b->loc_seqpos}) HIP_TRY(x->ensure(8 * (size_t)L));
+         HIP_TRY(b->loc_strand.ensure((size_t)L));
+         HIP_TRY(b->loc_score.ensure((size_t)L));
+         hipLaunchKernelGGL(k_unpack_locs, dim3((unsigned)cdiv(L, 256)), dim3(256), 0, st, ctx->ix,
+                            (const unsigned long long *)db.Current(), L, pos_bits, b->loc_read.as<int64_t>(),
+                            b->loc_pos.as<int64_t>(), b->loc_fwd.as<int64_t>(), b->loc_seq.as<int64_t>(),
+                            b->loc_seqpos.as<int64_t>(), b->loc_strand.as<uint8_t>(), b->loc_score.as<uint8_t>());
+         HIP_TRY(hipGetLastError());
+      }
+      if (want_intervals && H > 0) {
+         GM_FAIL_IF(R >= ((int64_t)1 << 24), "interval output supports at most 2^24 reads per batch.");
+         GM_FAIL_IF(H >= ((int64_t)1 << 31), "too many interval hits in one batch.");
+         HIP_TRY(b->hkeys.ensure(8 * (size_t)H)); HIP_TRY(b->hkeys_alt.ensure(8 * (size_t)H));
+         HIP_TRY(b->hidx.ensure(4 * (size_t)H)); HIP_TRY(b->hidx_alt.ensure(4 * (size_t)H));
+         hipLaunchKernelGGL(k_hit_keys, dim3((unsigned)cdiv(H, 256)), dim3(256), 0, st, b->hits.as<const Node>(), H,
+                            b->hkeys.as<unsigned long long>(), b->hidx.as<unsigned int>());
+         hipcub::DoubleBuffer<unsigned long long> dk(b->hkeys.as<unsigned long long>(), b->hkeys_alt.as<unsigned long long>());
+         hipcub::DoubleBuffer<unsigned int> dv(b->hidx.as<unsigned int>(), b->hidx_alt.as<unsigned int>());
+         size_t tmp = 0;
+         HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, dk, dv, (int)H, 0, 64, st));
+         HIP_TRY(ctx->cub_tmp.ensure(tmp));
+         HIP_TRY(hipcub::DeviceRadixSort::SortPairs(ctx->cub_tmp.p, tmp, dk, dv, (int)H, 0, 64, st));
+         for (DevBuf *x : {&b->hit_read, &b->hit_fp, &b->hit_rp, &b->hit_sz, &b->hit_dp, &b->hit_score}) HIP_TRY(x->ensure(8 * (size_t)H));
+         HIP_TRY(b->hit_align.ensure(32 * (size_t)H));
+         hipLaunchKernelGGL(k_unpack_hits, dim3((unsigned)cdiv(H, 256)), dim3(256), 0, st, b->hits.as<const Node>(),
+                            (const unsigned int *)dv.Current(), H, b->reads.as<const uint8_t>(), b->read_len.as<const uint16_t>(),
+                            b->stride, b->hit_read.as<int64_t>(), b->hit_fp.as<int64_t>(), b->hit_rp.as<int64_t>(),
+                            b->hit_sz.as<int64_t>(), b->hit_dp.as<int64_t>(), b->hit_score.as<int64_t>(), b->hit_align.as<uint64_t>());
+         HIP_TRY(hipGetLastError());
+      }
+      b->have_intervals = want_intervals != 0;
+      HIP_TRY(hipEventRecord(b->ev[3], st));
+      HIP_TRY(hipStreamSynchronize(st));
+      HIP_TRY(hipEventElapsedTime(&b->ms[0], b->ev[0], b->ev[1]));
+      HIP_TRY(hipEventElapsedTime(&b->ms[1], b->ev[1], b->ev[2]));
+      HIP_TRY(hipEventElapsedTime(&b->ms[2], b->ev[2], b->ev[3]));
+      HIP_TRY(hipEventElapsedTime(&b->ms[3], b->ev[0], b->ev[3]));
+      b->ran = true;
+   }
+   return 0;
+failure_return:
+   return -1;
+}
+
+extern "C" int gpumap_batch_counters(const gpumap_batch *b, int64_t *n_hits, int64_t *n_locs, int64_t *n_ext, float ms[4])
+{
+   GM_FAIL_IF(b == nullptr, "argument 'batch' is NULL.");
+   GM_FAIL_IF(!b->ran, "batch has not been run.");
+   if (n_hits) *n_hits = b->n_hits;
+   if (n_locs) *n_locs = b->n_locs;
+   if (n_ext) *n_ext = b->n_ext;
+   if (ms) for (int i = 0; i < 4; i++) ms[i] = b->ms[i];
+   return 0;
+failure_return:
+   return -1;
+}
+
+extern "C" void gpumap_hits_free(gpumap_hits *h)
+{
+   if (!h) return;
+   free(h->status); free(h->read_first_loc); free(h->loc_read); free(h->loc_pos); free(h->loc_fwd); free(h->loc_seq);
+   free(h->loc_seqpos); free(h->loc_strand); free(h->loc_score);
+   free(h->hit_read); free(h->hit_fp); free(h->hit_rp); free(h->hit_sz); free(h->hit_dp); free(h->hit_score); free(h->hit_align);
+   memset(h, 0, sizeof *h);
+}
+
+template <class T>
+static int fetch_array(T **dst, const DevBuf &src, int64_t count, hipStream_t st)
+{
+   *dst = (T *)malloc(sizeof(T) * (size_t)std::max<int64_t>(count, 1));
+   if (!*dst) return -1;
+   if (count > 0 && hipMemcpyAsync(*dst, src.p, sizeof(T) * (size_t)count, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
+   return 0;
+}
+
+extern "C" int gpumap_batch_fetch(gpumap_ctx *ctx, gpumap_batch *b, gpumap_hits *out)
+{
+   GM_FAIL_IF(ctx == nullptr || b == nullptr || out == nullptr, "NULL argument.");
+   GM_FAIL_IF(!b->ran, "batch has not been run.");
+   memset(out, 0, sizeof *out);
+   HIP_TRY(hipSetDevice(ctx->device));
+   {
+      hipStream_t st = ctx->stream;
+      const int64_t R = b->n_reads, L = b->n_locs, H = b->have_intervals ? b->n_hits : 0;
+      out->n_reads = R; out->n_locs = L; out->n_hits = H; out->n_ext = b->n_ext;
+      out->ms_search = b->ms[0]; out->ms_locate = b->ms[1]; out->ms_sort = b->ms[2]; out->ms_total = b->ms[3];
+      int rc = 0;
+      rc |= fetch_array(&out->status, b->status, R, st);
+      rc |= fetch_array(&out->read_first_loc, b->read_first, R + 1, st);
+      rc |= fetch_array(&out->loc_read, b->loc_read, L, st);
+      rc |= fetch_array(&out->loc_pos, b->loc_pos, L, st);
+      rc |= fetch_array(&out->loc_fwd, b->loc_fwd, L, st);
+      rc |= fetch_array(&out->loc_seq, b->loc_seq, L, st);
+      rc |= fetch_array(&out->loc_seqpos, b->loc_seqpos, L, st);
+      rc |= fetch_array(&out->loc_strand, b->loc_strand, L, st);
+      rc |= fetch_array(&out->loc_score, b->loc_score, L, st);
+      if (b->have_intervals) {
+         rc |= fetch_array(&out->hit_read, b->hit_read, H, st);
+         rc |= fetch_array(&out->hit_fp, b->hit_fp, H, st);
+         rc |= fetch_array(&out->hit_rp, b->hit_rp, H, st);
+         rc |= fetch_array(&out->hit_sz, b->hit_sz, H, st);
+         rc |= fetch_array(&out->hit_dp, b->hit_dp, H, st);
+         rc |= fetch_array(&out->hit_score, b->hit_score, H, st);
+         rc |= fetch_array(&out->hit_align, b->hit_align, 4 * H, st);
+      }
+      HIP_TRY(hipStreamSynchronize(st));
+      GM_FAIL_IF(rc != 0, "memory error.");
+   }
+   return 0;
+failure_return:
+   gpumap_hits_free(out);
+   return -1;
+}
+
+extern "C" int gpumap_map_batch(gpumap_ctx *ctx, const uint8_t *codes, const int64_t *offsets, int64_t n_reads,
+                                int tau, int want_intervals, gpumap_hits *out)
+{
+   gpumap_batch *b = nullptr;
+   GM_FAIL_IF(out == nullptr, "argument 'out' is NULL.");
+   memset(out, 0, sizeof *out);
+   b = gpumap_batch_upload(ctx, codes, offsets, n_reads);
+   GM_FAIL_IF(b == nullptr, "cannot upload the batch.");
+   GM_FAIL_IF(gpumap_batch_run(ctx, b, tau, want_intervals) != 0, "batch failed.");
+   GM_FAIL_IF(gpumap_batch_fetch(ctx, b, out) != 0, "cannot fetch results.");
+   gpumap_batch_free(b);
+   return 0;
+failure_return:
+   gpumap_batch_free(b);
+   return -1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// mapper() (src/mapper.c:3-47): chunks of reads -> GPU batches -> one line per located hit.
+// ------------------------------------------------------------------------------------------------
+extern "C" int gpumap_mapper(const char *qfile, const gpumap_index *index, gpumap_ctx *ctx, int tau, const char *out_path)
+{
+   gm_read_stream *in = nullptr;
+   FILE *fo = nullptr;
+   gpumap_batch *b = nullptr;
+   gpumap_hits h;
+   memset(&h, 0, sizeof h);
+   GM_FAIL_IF(qfile == nullptr, "argument 'qfile' is NULL.");
+   GM_FAIL_IF(index == nullptr, "argument 'index' is NULL.");
+   GM_FAIL_IF(ctx == nullptr, "argument 'ctx' is NULL.");
+   in = gm_reads_open(qfile);
+   GM_FAIL_IF(in == nullptr, "cannot open the read file.");
+   fo = (out_path == nullptr || !strcmp(out_path, "-")) ? stdout : fopen(out_path, "w");
+   GM_FAIL_IF(fo == nullptr, "cannot open the output file.");
+   {
+      gm_read_chunk chunk;
+      int64_t n;
+      const gpumap_index_view &v = index->view;
+      while ((n = gm_reads_next(in, (size_t)256 << 20 /* IO_DEFAULT_BUFSIZE, src/io.h:13 */, &chunk)) > 0) {
+         fprintf(stderr, "read: %ld sequences.\n", (long)n);                    // src/mapper.c:30
+         b = gpumap_batch_upload_text(ctx, chunk.text.data(), chunk.offsets.data(), n);
+         GM_FAIL_IF(b == nullptr, "cannot upload the batch.");
+         GM_FAIL_IF(gpumap_batch_run(ctx, b, tau, 0) != 0, "batch failed.");
+         GM_FAIL_IF(gpumap_batch_fetch(ctx, b, &h) != 0, "cannot fetch results.");
+         gpumap_batch_free(b); b = nullptr;
+         for (int64_t t = 0; t < h.n_locs; t++)
+            fprintf(fo, "%s\t%s:%ld:%c\t%d\n", chunk.tags[(size_t)h.loc_read[t]].c_str(), v.seq_name[h.loc_seq[t]],
+                    (long)h.loc_seqpos[t], h.loc_strand[t] ? '-' : '+', (int)h.loc_score[t]);
+         gpumap_hits_free(&h);
+      }
+      GM_FAIL_IF(n < 0, "error while reading the read file.");
+   }
+   if (fo != stdout) fclose(fo);
+   gm_reads_close(in);
+   return 0;
+failure_return:
+   gpumap_batch_free(b);
+   gpumap_hits_free(&h);
+   if (fo && fo != stdout) fclose(fo);
+   gm_reads_close(in);
+   return -1;
+}

@@ -1,0 +1,594 @@
+// gm_kernels.hpp -- HIP kernels of the query hot path (gfx950 / CDNA4, wave64).
+//
+//   k_super_counts, k_pack_blocks   K0  reference Occ layout -> 64-byte rank blocks (one-off)
+//   k_search                        K2  block search for a batch of reads (the hot kernel)
+//   k_expand_hits                   K3  suffix-array locate as a flat, balanced gather
+//   k_encode                        K4  letters -> codes, fixed-stride read matrix
+//   k_occ_all, k_query_all, k_sar_get   batched forms of the reference's single-query operators
+//
+// Design notes (DESIGN.md has the long form):
+//  * The path is integer and gather-bound: no MFMA.  What is tuned is the number of cache lines
+//    touched per extension step and the number of independent chains in flight.
+//  * Four neighbouring lanes ("quad") own one search node.  A rank query is one 16-byte load per
+//    lane (one 64-byte line per quad, fully used), a popcount over 32 positions per lane and two
+//    DPP quad_perm adds.  In branching steps lane k of the quad evaluates the child for symbol k.
+//  * The recursion of the reference (seqsearch_* calling itself, the pathstack_t per tree level)
+//    becomes a per-wavefront deque of 32-byte nodes in LDS: pushes are compacted with
+//    __ballot + popcount prefix, pops hand the newest nodes to idle quads (LIFO keeps the
+//    frontier small); the oldest part of the deque spills to a per-wave global buffer when full.
+//  * Exact continuation (the "dash", most steps) keeps its node in registers: no LDS traffic.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "gm_core.hpp"
+
+namespace gm {
+
+constexpr int WG_WAVES = 4;
+constexpr int WG_THREADS = 64 * WG_WAVES;
+constexpr int QCAP = 256;            // deque capacity per wave (nodes), power of two
+constexpr int SPILL_CHUNK = 128;     // nodes moved per spill / reload
+constexpr int MAX_SB_LDS = 256;      // superblocks whose counts are staged in LDS (n < 2^33)
+
+// Layout of the small `tables` buffer (64-bit words): [0..4] C[0..4]; [8 + 5*s + j] absolute count
+// of symbol j in BWT[0, s << 25).
+constexpr int TAB_C = 0;
+constexpr int TAB_SBASE = 8;
+
+struct IndexDev {
+   const uint32_t *occ;        // rank blocks, 16 dwords each
+   const uint64_t *tables;
+   const uint64_t *sa;         // packed suffix array, verbatim
+   const int64_t  *seq_beg;
+   int64_t n;                  // text length
+   int64_t n_blocks, n_super;
+   int32_t sar_bits;
+   int32_t seq_cnt;
+};
+
+// ------------------------------------------------------------------------------------------------
+// K0: repack
+// ------------------------------------------------------------------------------------------------
+
+// Counts of the five symbols in BWT[0, e) from the reference's array (the arithmetic of
+// get_occ_all, src/index_bwt.c:863-883, always from the mark before the word).
+// __noinline__: inlined into a kernel, this function makes hipcc 7.2's correlated-propagation pass
+// crash; it only runs in the one-off repack, so the call costs nothing that matters.
+__device__ __noinline__ void ref_rank_excl(const uint64_t *occ, int64_t intv, int64_t e, uint64_t cnt[SYMS])
+{
+   int64_t w = e >> 6;
+   int bit = (int)(e & 63);
+   int64_t mk = w / intv;
+   const uint64_t *m = occ + mk * (intv + 1) * SYMS;
+   for (int j = 0; j < SYMS; j++) cnt[j] = m[j];
+   for (int64_t ww = mk * intv; ww < w; ww++) {
+      const uint64_t *g = occ + (ww + ww / intv + 1) * SYMS;
+      for (int j = 0; j < SYMS; j++) cnt[j] += __popcll(g[j]);
+   }
+   if (bit) {
+      const uint64_t *g = occ + (w + w / intv + 1) * SYMS;
+      for (int j = 0; j < SYMS; j++) cnt[j] += __popcll(g[j] >> (64 - bit));
+   }
+}
+
+__global__ void k_super_counts(const uint64_t *ref_occ, int64_t intv, int64_t n, int64_t n_super,
+                               const uint64_t *c, uint64_t *tables)
+{
+   int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+   if (s < SYMS) tables[TAB_C + s] = c[s];
+   if (s >= n_super) return;
+   uint64_t cnt[SYMS];
+   int64_t e = s << SUPER_LOG;
+   if (e > n) e = n;
+   ref_rank_excl(ref_occ, intv, e, cnt);
+   for (int j = 0; j < SYMS; j++) tables[TAB_SBASE + SYMS * s + j] = cnt[j];
+}
+
+struct PackArgs {
+   const uint64_t *ref_occ;
+   const uint64_t *tables;
+   uint32_t *blocks;
+   int64_t intv, n_ref_words, n_blocks;
+};
+
+__global__ void k_pack_blocks(PackArgs P)
+{
+   int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+   if (b >= P.n_blocks) return;
+   int64_t e = b << BLOCK_POS_LOG;
+   uint64_t cnt[SYMS];
+   ref_rank_excl(P.ref_occ, P.intv, e, cnt);
+   uint32_t rel[SYMS];
+   const uint64_t *base = P.tables + TAB_SBASE + SYMS * (e >> SUPER_LOG);
+   for (int j = 0; j < SYMS; j++) rel[j] = (uint32_t)(cnt[j] - base[j]);
+   uint32_t out[BLOCK_DWORDS];
+   pack_block(P.ref_occ, P.intv, P.n_ref_words, b, rel, out);
+   uint4 *dst = reinterpret_cast<uint4 *>(P.blocks) + 4 * b;
+   for (int k = 0; k < 4; k++) dst[k] = make_uint4(out[4 * k], out[4 * k + 1], out[4 * k + 2], out[4 * k + 3]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Single-thread rank / extension (operator kernels and locate; not the hot path)
+// ------------------------------------------------------------------------------------------------
+
+__device__ inline void rank_abs(const IndexDev &ix, int64_t e, int64_t occ[SYMS])
+{
+   uint32_t rel[SYMS];
+   block_rank(ix.occ + (e >> BLOCK_POS_LOG) * BLOCK_DWORDS, (int)(e & (BLOCK_POS - 1)), rel);
+   const uint64_t *base = ix.tables + TAB_SBASE + SYMS * (e >> SUPER_LOG);
+   for (int j = 0; j < SYMS; j++) occ[j] = (int64_t)(base[j] + rel[j]);
+}
+
+// get_occ_all for n positions (src/index_bwt.c:840-905): ptr = -1 gives zeros.
+__global__ void k_occ_all(IndexDev ix, int64_t n, const int64_t *ptr, int64_t *out)
+{
+   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+   if (i >= n) return;
+   int64_t p = ptr[i];
+   int64_t occ[SYMS] = {-1, -1, -1, -1, -1};
+   if (p >= -1 && p < ix.n) rank_abs(ix, p + 1, occ);
+   for (int j = 0; j < SYMS; j++) out[SYMS * i + j] = occ[j];
+}
+
+// bwt_query_all for n intervals (src/index_bwt.c:198-304).
+__global__ void k_query_all(IndexDev ix, int end, int64_t n, const int64_t *fp, const int64_t *rp,
+                            const int64_t *sz, int64_t *out)
+{
+   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+   if (i >= n) return;
+   int64_t a = end ? rp[i] : fp[i], other = end ? fp[i] : rp[i], s = sz[i];
+   int64_t *o = out + 15 * i;
+   if (a < 0 || s < 0 || a + s > ix.n) { for (int k = 0; k < 15; k++) o[k] = -1; return; }
+   int64_t occ0[SYMS], occ1[SYMS], fpn[SYMS], rpn[SYMS], szn[SYMS];
+   uint64_t c[SYMS];
+   for (int j = 0; j < SYMS; j++) c[j] = ix.tables[TAB_C + j];
+   rank_abs(ix, a, occ0);
+   rank_abs(ix, a + s, occ1);
+   extend_all(other, s, occ0, occ1, c, fpn, rpn, szn);
+   for (int j = 0; j < SYMS; j++) {
+      int js = end ? complement(j) : j;                      // :280-286
+      o[3 * j + 0] = end ? rpn[js] : fpn[js];
+      o[3 * j + 1] = end ? fpn[js] : rpn[js];
+      o[3 * j + 2] = szn[js];
+   }
+}
+
+// sar_get (src/index_sar.c:92-118): entry i = bits [i*b, (i+1)*b) of the little-endian stream.
+__device__ inline int64_t sa_entry(const uint64_t *sa, int bits, int64_t i)
+{
+   uint64_t bit = (uint64_t)i * (uint64_t)bits;
+   uint64_t w = bit >> 6;
+   int sh = (int)(bit & 63);
+   uint64_t v = sa[w] >> sh;
+   if (sh + bits > 64) v |= sa[w + 1] << (64 - sh);
+   return (int64_t)(v & (~(uint64_t)0 >> (64 - bits)));
+}
+
+__global__ void k_sar_get(IndexDev ix, int64_t n, const int64_t *pos, int64_t *out)
+{
+   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+   if (i >= n) return;
+   int64_t p = pos[i];
+   out[i] = (p < 0 || p >= ix.n) ? -1 : sa_entry(ix.sa, ix.sar_bits, p);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4: reads.  Letters (or codes) -> codes in a fixed-stride matrix [n_reads][stride].
+// ------------------------------------------------------------------------------------------------
+__global__ void k_encode(const uint8_t *src, const int64_t *offsets, int64_t n_reads, int stride,
+                         const uint8_t *table /* 256 entries, or nullptr for codes */, uint8_t *dst,
+                         uint16_t *read_len, uint8_t *flat_codes /* optional, same layout as src */)
+{
+   int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+   int64_t r = t / stride;
+   int p = (int)(t - r * stride);
+   if (r >= n_reads) return;
+   int64_t beg = offsets[r], len = offsets[r + 1] - beg;
+   if (p == 0) read_len[r] = (uint16_t)(len < 0 ? 0 : (len > 0xffff ? 0xffff : len));
+   uint8_t code = 0xff;
+   if (p < len) {
+      uint8_t s = src[beg + p];
+      code = table ? table[s] : (s < SYMS ? s : (uint8_t)UNKNOWN);
+      if (flat_codes) flat_codes[beg + p] = code;
+   }
+   dst[t] = code;
+}
+
+// Flat variant for gpumap_encode: sym_str_index (src/index_sym.c:293-319) over a whole buffer.
+__global__ void k_encode_flat(const uint8_t *src, int64_t n, const uint8_t *table, uint8_t *dst)
+{
+   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+   if (i < n) dst[i] = table[src[i]];
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: the search
+// ------------------------------------------------------------------------------------------------
+struct SearchArgs {
+   IndexDev ix;
+   const uint8_t  *reads;       // [n_reads][stride] codes
+   const uint16_t *read_len;    // [n_reads]
+   const uint8_t  *len_row;     // [MAX_READ + 1] -> row of `phases`, 0xff = the reference returns -1
+   const uint32_t *phases;      // [rows][MAX_PHASES]
+   int64_t n_reads;
+   int stride, tau;
+   unsigned long long *cursor;  // next read to admit
+   Node *hits;                  // finished nodes
+   unsigned long long hit_cap;
+   unsigned long long *hit_count;
+   unsigned long long *n_ext;   // extension steps executed
+   Node *spill;                 // [waves][spill_cap]
+   uint32_t spill_cap;
+   int *error;                  // set to 1 when a spill region overflows
+};
+
+__device__ __forceinline__ uint32_t quad_sum(uint32_t x)
+{
+   x += (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+   x += (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+   return x;
+}
+
+template <class T>
+__device__ __forceinline__ T sel5(const T v[SYMS], int j)
+{
+   T r = v[0];
+   r = j == 1 ? v[1] : r;
+   r = j == 2 ? v[2] : r;
+   r = j == 3 ? v[3] : r;
+   r = j == 4 ? v[4] : r;
+   return r;
+}
+
+__device__ __forceinline__ void lds_store_node(Node *q, uint32_t slot, const Node &nd)
+{
+   uint4 *d = reinterpret_cast<uint4 *>(q + (slot & (QCAP - 1)));
+   d[0] = make_uint4(nd.w[0], nd.w[1], nd.w[2], nd.w[3]);
+   d[1] = make_uint4(nd.w[4], nd.w[5], nd.w[6], nd.w[7]);
+}
+
+__device__ __forceinline__ void lds_load_node(const Node *q, uint32_t slot, Node &nd)
+{
+   const uint4 *s = reinterpret_cast<const uint4 *>(q + (slot & (QCAP - 1)));
+   uint4 a = s[0], b = s[1];
+   nd.w[0] = a.x; nd.w[1] = a.y; nd.w[2] = a.z; nd.w[3] = a.w;
+   nd.w[4] = b.x; nd.w[5] = b.y; nd.w[6] = b.z; nd.w[7] = b.w;
+}
+
+__device__ __forceinline__ void wave_sync()
+{
+   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+   __builtin_amdgcn_wave_barrier();
+}
+
+struct WaveQueue {
+   Node *q;
+   Node *spill;
+   uint32_t bot, top, spill_top, spill_cap;
+   int *error;
+};
+
+// Converged call: every lane of the wave executes it.  Lanes with `flag` append `nd`.
+__device__ __forceinline__ void wave_push(WaveQueue &wq, bool flag, const Node &nd, int lane)
+{
+   if (wq.top - wq.bot + 64 > QCAP) {
+      // Spill the oldest SPILL_CHUNK nodes (LIFO order is kept: they return only when the deque is empty).
+      bool room = wq.spill_top + SPILL_CHUNK <= wq.spill_cap;
+      if (room) {
+         for (int i = lane; i < SPILL_CHUNK; i += 64) {
+            Node t;
+            lds_load_node(wq.q, wq.bot + i, t);
+            uint4 *d = reinterpret_cast<uint4 *>(wq.spill + wq.spill_top + i);
+            d[0] = make_uint4(t.w[0], t.w[1], t.w[2], t.w[3]);
+            d[1] = make_uint4(t.w[4], t.w[5], t.w[6], t.w[7]);
+         }
+         wq.spill_top += SPILL_CHUNK;
+      } else if (lane == 0) {
+         *wq.error = 1;      // results are incomplete; the host reports the failure
+      }
+      wq.bot += SPILL_CHUNK;
+      wave_sync();
+   }
+   unsigned long long m = __ballot(flag);
+   if (flag) lds_store_node(wq.q, wq.top + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), nd);
+   wq.top += (uint32_t)__popcll(m);
+}
+
+// Converged call: lanes with `flag` append `nd` to the global hit list.
+__device__ __forceinline__ void wave_emit(const SearchArgs &A, bool flag, const Node &nd, int lane)
+{
+   unsigned long long m = __ballot(flag);
+   if (m == 0) return;
+   unsigned long long base = 0;
+   int leader = __ffsll((long long)m) - 1;
+   if (lane == leader) base = atomicAdd(A.hit_count, (unsigned long long)__popcll(m));
+   base = __shfl(base, leader);
+   if (flag) {
+      unsigned long long at = base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
+      if (at < A.hit_cap) {
+         uint4 *d = reinterpret_cast<uint4 *>(A.hits + at);
+         d[0] = make_uint4(nd.w[0], nd.w[1], nd.w[2], nd.w[3]);
+         d[1] = make_uint4(nd.w[4], nd.w[5], nd.w[6], nd.w[7]);
+      }
+   }
+}
+
+__global__ void __launch_bounds__(WG_THREADS) k_search(SearchArgs A)
+{
+   __shared__ Node s_q[WG_WAVES][QCAP];
+   __shared__ unsigned long long s_cb[MAX_SB_LDS * SYMS];    // C[j] + count of j before superblock s
+
+   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, sub = lane & 3;
+   const uint32_t gw = blockIdx.x * WG_WAVES + wid;
+   for (int i = tid; i < (int)A.ix.n_super * SYMS; i += WG_THREADS)
+      s_cb[i] = A.ix.tables[TAB_SBASE + i] + A.ix.tables[TAB_C + i % SYMS];
+   __syncthreads();
+
+   WaveQueue wq;
+   wq.q = s_q[wid];
+   wq.spill = A.spill + (size_t)gw * A.spill_cap;
+   wq.bot = wq.top = wq.spill_top = 0;
+   wq.spill_cap = A.spill_cap;
+   wq.error = A.error;
+
+   const int seeds_per = A.tau + 1;
+   const int reads_per_refill = 64 / seeds_per;
+   const unsigned long long lt_mask = (1ull << lane) - 1ull;
+   const uint4 *occ4 = reinterpret_cast<const uint4 *>(A.ix.occ);
+
+   bool reads_left = true;
+   bool have = false;
+   NodeR cur;
+   cur.fp = cur.rp = cur.sz = 0; cur.read = 0; cur.mm = 0;
+   cur.pos = cur.end = cur.phase = cur.score = cur.sref = cur.tau = cur.diff = 0;
+   cur.dash = cur.fw = false;
+   unsigned long long ext_count = 0;
+
+   for (;;) {
+      // ------------------------------------------------------------ hand nodes to idle quads
+      unsigned long long needm = __ballot(!have && sub == 0);
+      int nneed = __popcll(needm);
+      if (nneed) {
+         int count = (int)(wq.top - wq.bot);
+         if (count < nneed) {
+            if (wq.spill_top > 0) {
+               wq.spill_top -= SPILL_CHUNK;
+               for (int i = lane; i < SPILL_CHUNK; i += 64) {
+                  const uint4 *s = reinterpret_cast<const uint4 *>(wq.spill + wq.spill_top + i);
+                  uint4 a = s[0], b = s[1];
+                  Node t;
+                  t.w[0] = a.x; t.w[1] = a.y; t.w[2] = a.z; t.w[3] = a.w;
+                  t.w[4] = b.x; t.w[5] = b.y; t.w[6] = b.z; t.w[7] = b.w;
+                  lds_store_node(wq.q, wq.top + i, t);
+               }
+               wq.top += SPILL_CHUNK;
+            } else if (reads_left) {
+               // Admit reads: one seed per leaf block of the schedule (src/blocksearch.c:138-144).
+               unsigned long long base = 0;
+               if (lane == 0) base = atomicAdd(A.cursor, (unsigned long long)reads_per_refill);
+               base = __shfl(base, 0);
+               if (base >= (unsigned long long)A.n_reads) {
+                  reads_left = false;
+               } else {
+                  int got = (int)min((unsigned long long)reads_per_refill, (unsigned long long)A.n_reads - base);
+                  int r = lane / seeds_per, leaf = lane - r * seeds_per;
+                  bool mk = r < got;
+                  Node packed;
+                  for (int k = 0; k < 8; k++) packed.w[k] = 0;
+                  if (mk) {
+                     uint32_t read = (uint32_t)(base + r);
+                     int m = A.read_len[read];
+                     int row = m <= MAX_READ ? A.len_row[m] : 0xff;
+                     mk = row != 0xff;
+                     if (mk) {
+                        NodeR sd;
+                        sd.fp = 0; sd.rp = 0; sd.sz = A.ix.n;        // bwt_new_query, src/index_bwt.c:48-52
+                        sd.read = read; sd.score = 0; sd.mm = (uint64_t)row << 56;
+                        sd.sref = 0; sd.pos = sd.end = sd.tau = sd.diff = sd.phase = 0; sd.dash = sd.fw = false;
+                        enter_phase(sd, leaf, A.phases[row * MAX_PHASES + leaf]);
+                        pack_node(sd, packed);
+                     }
+                  }
+                  wave_push(wq, mk, packed, lane);
+               }
+            }
+            wave_sync();
+            count = (int)(wq.top - wq.bot);
+         }
+         if (!have) {
+            int rank = __popcll(needm & ((1ull << (lane & ~3)) - 1ull));
+            if (rank < count) {
+               Node nd;
+               lds_load_node(wq.q, wq.top - 1 - (uint32_t)rank, nd);
+               unpack_node(nd, cur);
+               have = true;
+            }
+         }
+         wq.top -= (uint32_t)min(nneed, count);
+         wave_sync();
+      }
+      if (!__any(have)) {
+         if (!reads_left && wq.spill_top == 0 && wq.top == wq.bot) break;
+         continue;
+      }
+      ext_count += (unsigned long long)__popcll(__ballot(have && sub == 0));
+
+      // ------------------------------------------------------------ one extension step per quad
+      bool push1 = false, emit1 = false, push2 = false, emit2 = false, branching = false;
+      Node out1, out2;
+      for (int k = 0; k < 8; k++) { out1.w[k] = 0; out2.w[k] = 0; }
+      if (have) {
+         const int64_t a = cur.fw ? cur.rp : cur.fp, other = cur.fw ? cur.fp : cur.rp;
+         const int64_t e0 = a, e1 = a + cur.sz;                       // ranks at a-1 and a+sz-1, exclusive form
+         const int64_t b0 = e0 >> BLOCK_POS_LOG, b1 = e1 >> BLOCK_POS_LOG;
+         uint4 v0 = occ4[b0 * 4 + sub];
+         uint4 v1 = v0;
+         if (b1 != b0) v1 = occ4[b1 * 4 + sub];
+         const int qc = A.reads[(size_t)cur.read * A.stride + cur.pos];
+         const int row = (int)(cur.mm >> 56);
+
+         int t0 = (int)(e0 & (BLOCK_POS - 1)) - 32 * sub; t0 = t0 < 0 ? 0 : (t0 > 32 ? 32 : t0);
+         int t1 = (int)(e1 & (BLOCK_POS - 1)) - 32 * sub; t1 = t1 < 0 ? 0 : (t1 > 32 ? 32 : t1);
+         uint32_t c0[SYMS], c1[SYMS];
+         sub_counts(v0.x, v0.y, v0.z, t0, c0);
+         sub_counts(v1.x, v1.y, v1.z, t1, c1);
+         // running counts: lane k carries symbol k's 25-bit count and 7 bits of N's
+         uint32_t own0 = v0.w & CNT_MASK, own1 = v1.w & CNT_MASK;
+         c0[0] += sub == 0 ? own0 : 0; c0[1] += sub == 1 ? own0 : 0; c0[2] += sub == 2 ? own0 : 0; c0[3] += sub == 3 ? own0 : 0;
+         c1[0] += sub == 0 ? own1 : 0; c1[1] += sub == 1 ? own1 : 0; c1[2] += sub == 2 ? own1 : 0; c1[3] += sub == 3 ? own1 : 0;
+         c0[4] += (v0.w >> 25) << (7 * sub);
+         c1[4] += (v1.w >> 25) << (7 * sub);
+         for (int j = 0; j < SYMS; j++) { c0[j] = quad_sum(c0[j]); c1[j] = quad_sum(c1[j]); }
+
+         const int sb0 = (int)(e0 >> SUPER_LOG), sb1 = (int)(e1 >> SUPER_LOG);
+         int64_t szn[SYMS], rpn[SYMS];
+         for (int j = 0; j < SYMS; j++) szn[j] = (int64_t)c1[j] - (int64_t)c0[j];
+         if (sb1 != sb0)
+            for (int j = 0; j < SYMS; j++) szn[j] += (int64_t)(s_cb[sb1 * SYMS + j] - s_cb[sb0 * SYMS + j]);
+         // bwt_query_all, src/index_bwt.c:262-273
+         int64_t tot = szn[0] + szn[1] + szn[2] + szn[3] + szn[4];
+         rpn[3] = other + (cur.sz - tot);
+         rpn[2] = rpn[3] + szn[3];
+         rpn[1] = rpn[2] + szn[2];
+         rpn[0] = rpn[1] + szn[1];
+         rpn[4] = rpn[0] + szn[0];
+
+         const bool sticky = cur.dash && qc != UNKNOWN;
+         branching = !sticky;
+         {
+            const int nt = sticky ? qc : sub;
+            const int js = cur.fw ? complement(nt) : nt;
+            const int64_t fpn = (int64_t)(s_cb[sb0 * SYMS + js] + sel5(c0, js));
+            const int64_t rp_ = sel5(rpn, js), sz_ = sel5(szn, js);
+            NodeR child;
+            int kind = make_child(cur, nt, qc, cur.fw ? rp_ : fpn, cur.fw ? fpn : rp_, sz_, child);
+            bool done_final = false;
+            if (kind == CHILD_DONE) {
+               int nxt = phase_next(A.phases[row * MAX_PHASES + cur.phase]);
+               if (nxt == PHASE_FINAL) done_final = true;
+               else { enter_phase(child, nxt, A.phases[row * MAX_PHASES + nxt]); kind = CHILD_NODE; }
+            }
+            if (sticky) {
+               if (done_final) { emit1 = sub == 0; child.pos = 0; pack_node(child, out1); have = false; }
+               else if (kind == CHILD_NODE) cur = child;
+               else have = false;
+            } else {
+               if (done_final) { emit1 = true; child.pos = 0; pack_node(child, out1); }
+               else if (kind == CHILD_NODE) { push1 = true; pack_node(child, out1); }
+            }
+         }
+         // text N as a branch (nt = 4): explored like any other symbol (src/blocksearch.c:207)
+         if (branching && sub == 0 && szn[4] >= 1) {
+            const int64_t fpn = (int64_t)(s_cb[sb0 * SYMS + 4] + c0[4]);
+            NodeR child;
+            int kind = make_child(cur, 4, qc, cur.fw ? rpn[4] : fpn, cur.fw ? fpn : rpn[4], szn[4], child);
+            if (kind == CHILD_DONE) {
+               int nxt = phase_next(A.phases[row * MAX_PHASES + cur.phase]);
+               if (nxt == PHASE_FINAL) { emit2 = true; child.pos = 0; pack_node(child, out2); kind = CHILD_NONE; }
+               else { enter_phase(child, nxt, A.phases[row * MAX_PHASES + nxt]); kind = CHILD_NODE; }
+            }
+            if (kind == CHILD_NODE) { push2 = true; pack_node(child, out2); }
+         }
+         if (branching) have = false;
+      }
+      // ------------------------------------------------------------ converged: queue and hit traffic
+      if (__any(push1)) { wave_push(wq, push1, out1, lane); }
+      if (__any(push2)) { wave_push(wq, push2, out2, lane); }
+      wave_emit(A, emit1, out1, lane);
+      wave_emit(A, emit2, out2, lane);
+      wave_sync();
+      (void)lt_mask;
+   }
+   if (lane == 0 && ext_count) atomicAdd(A.n_ext, ext_count);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3: locate.  hit_off = exclusive scan of the hit sizes.  Output slot t belongs to the hit h with
+// hit_off[h] <= t < hit_off[h+1]; consecutive slots of one hit read consecutive packed SA entries
+// (sar_get_range, src/index_sar.c:121-161), so a wave reads a contiguous bit range.
+// key = read << (pos_bits + 4) | text position << 4 | score: one radix sort then orders the hits by
+// read and, inside a read, by text position.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_hit_sizes(const Node *hits, int64_t n_hits, int64_t *sizes)
+{
+   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+   if (i >= n_hits) return;
+   sizes[i] = (int64_t)hits[i].w[2] | ((int64_t)((hits[i].w[3] >> 16) & 0xff) << 32);
+}
+
+__global__ void k_expand_hits(IndexDev ix, const Node *hits, int64_t n_hits, const int64_t *hit_off,
+                              int64_t n_locs, int pos_bits, unsigned long long *keys,
+                              unsigned int *read_cnt)
+{
+   int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+   if (t >= n_locs) return;
+   int64_t lo = 0, hi = n_hits;             // last h with hit_off[h] <= t
+   while (hi - lo > 1) { int64_t mid = (lo + hi) >> 1; if (hit_off[mid] <= t) lo = mid; else hi = mid; }
+   NodeR h;
+   unpack_node(hits[lo], h);
+   int64_t pos = sa_entry(ix.sa, ix.sar_bits, h.fp + (t - hit_off[lo]));
+   keys[t] = ((unsigned long long)h.read << (pos_bits + 4)) | ((unsigned long long)pos << 4) | (unsigned long long)h.score;
+   atomicAdd(read_cnt + h.read, 1u);
+}
+
+// Sorted keys -> structure of arrays; strand and coordinates by the rule of txt_pos_to_str
+// (src/index_txt.c:492-505) with seq_bisect (:770-787).
+__global__ void k_unpack_locs(IndexDev ix, const unsigned long long *keys, int64_t n_locs, int pos_bits,
+                              int64_t *loc_read, int64_t *loc_pos, int64_t *loc_fwd, int64_t *loc_seq,
+                              int64_t *loc_seqpos, uint8_t *loc_strand, uint8_t *loc_score)
+{
+   int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+   if (t >= n_locs) return;
+   unsigned long long k = keys[t];
+   int64_t pos = (int64_t)((k >> 4) & ((1ull << pos_bits) - 1ull));
+   loc_read[t] = (int64_t)(k >> (pos_bits + 4));
+   loc_pos[t] = pos;
+   loc_score[t] = (uint8_t)(k & 15);
+   int strand = pos >= ix.n / 2;
+   int64_t f = strand ? ix.n - 2 - pos : pos;
+   loc_strand[t] = (uint8_t)strand;
+   loc_fwd[t] = f;
+   int64_t lo = 0, hi = ix.seq_cnt;
+   while (hi - lo >= 2) { int64_t mid = (lo + hi) / 2; if (f < ix.seq_beg[mid]) hi = mid; else lo = mid; }
+   loc_seq[t] = lo;
+   loc_seqpos[t] = f - ix.seq_beg[lo] + 1;
+}
+
+// Interval hits -> sortable keys (read, fp) and, after the sort, structure of arrays with the
+// mismatch bitmap rebuilt from the recorded positions and the query's N positions.
+__global__ void k_hit_keys(const Node *hits, int64_t n_hits, unsigned long long *keys, unsigned int *idx)
+{
+   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+   if (i >= n_hits) return;
+   NodeR h;
+   unpack_node(hits[i], h);
+   keys[i] = ((unsigned long long)h.read << 40) | (unsigned long long)h.fp;   // reads < 2^24 per run, fp < 2^40
+   idx[i] = (unsigned int)i;
+}
+
+__global__ void k_unpack_hits(const Node *hits, const unsigned int *idx, int64_t n_hits, const uint8_t *reads,
+                              const uint16_t *read_len, int stride, int64_t *hit_read, int64_t *hit_fp,
+                              int64_t *hit_rp, int64_t *hit_sz, int64_t *hit_dp, int64_t *hit_score,
+                              uint64_t *hit_align_out)
+{
+   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+   if (i >= n_hits) return;
+   NodeR h;
+   unpack_node(hits[idx[i]], h);
+   int m = read_len[h.read];
+   hit_read[i] = h.read; hit_fp[i] = h.fp; hit_rp[i] = h.rp; hit_sz[i] = h.sz;
+   hit_dp[i] = m;                       // one extension per letter (dp + 1 per bwt_query_all)
+   hit_score[i] = h.score;
+   uint64_t al[4];
+   hit_align(h.mm, h.score, reads + (size_t)h.read * stride, m, al);
+   for (int w = 0; w < 4; w++) hit_align_out[4 * i + w] = al[w];
+}
+
+__global__ void k_status(const uint16_t *read_len, const uint8_t *len_row, int64_t n_reads, int64_t *status)
+{
+   int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+   if (r >= n_reads) return;
+   int m = read_len[r];
+   status[r] = (m <= MAX_READ && len_row[m] != 0xff) ? 0 : -1;
+}
+
+}  // namespace gm

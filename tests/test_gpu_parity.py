@@ -1,0 +1,195 @@
+"""GPU parity tests: the HIP path, called through the C-ABI, against the oracle and the golden dumps
+of the reference.  Bit-exact (integer work): every comparison is array equality."""
+import os
+
+import numpy as np
+import pytest
+
+import mapper_amd as ma
+from mapper_amd import synth
+from oracle import pyoracle as po
+from tests import common
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def small(workdir):
+    base = common.build_golden_index(workdir, "small")
+    ctx = ma.Context.from_files(base, 0)
+    yield base, ctx, po.Index(base)
+    ctx.close()
+
+
+def test_occ_all_matches_oracle(small):
+    base, ctx, orc = small
+    n = orc.txt_len
+    rng = np.random.default_rng(1)
+    ptr = np.concatenate(([-1, 0, 1, 126, 127, 128, 129, n - 2, n - 1], rng.integers(-1, n, 5000)))
+    got = ctx.occ_all(ptr)
+    want = np.array([orc.occ_all(int(p)) for p in ptr])
+    assert np.array_equal(got, want)
+
+
+def test_query_all_matches_oracle(small):
+    base, ctx, orc = small
+    n = orc.txt_len
+    rng = np.random.default_rng(2)
+    # walk random bidirectional extensions from the root
+    fp, rp, sz = [0], [0], [n]
+    cur = [(0, 0, n)]
+    for depth in range(12):
+        nxt = []
+        for (f, r, s) in cur:
+            for end in (0, 1):
+                ch = orc.extend_all(end, f, r, s)
+                for j in range(5):
+                    if ch[j][2] > 0 and rng.random() < 0.35:
+                        nxt.append(ch[j])
+        cur = nxt[:200] or cur
+        for (f, r, s) in cur:
+            fp.append(f); rp.append(r); sz.append(s)
+    for end in (ma.QUERY_PREFIX, ma.QUERY_SUFFIX):
+        got = ctx.query_all(end, fp, rp, sz)
+        want = np.array([orc.extend_all(end, f, r, s) for f, r, s in zip(fp, rp, sz)])
+        assert np.array_equal(got, want)
+
+
+def test_sar_get_matches_oracle(small):
+    base, ctx, orc = small
+    n = orc.txt_len
+    pos = np.arange(n)
+    got = ctx.sar_get(pos)
+    want = np.array(orc.sar_get_range(0, n))
+    assert np.array_equal(got, want)
+    assert sorted(got.tolist()) == list(range(n))          # a suffix array is a permutation
+    assert np.array_equal(ctx.sar_get_range(5, 100), want[5:105])
+    assert np.array_equal(ctx.sar_get([-1, n, n + 5]), [-1, -1, -1])
+
+
+@pytest.mark.parametrize("tau", [0, 1, 2, 3, 4])
+def test_map_small_matches_reference_dump(small, tau):
+    base, ctx, orc = small
+    reads = common.load_reads("small.reads.txt")
+    codes, offs = common.encode_reads(reads)
+    ref = po.HitDump.load(os.path.join(common.GOLDEN, "small.tau%d.bin" % tau))
+    h = ctx.map_batch(codes, offs, tau, want_intervals=True)
+    assert np.array_equal(h.status, ref.status)
+    assert np.array_equal(h.located(), ref.located())
+    assert np.array_equal(h.intervals(), ref.intervals())
+    # CSR offsets
+    cnt = np.bincount(ref.located()[:, 0], minlength=len(reads)) if len(ref.located()) else np.zeros(len(reads), int)
+    assert np.array_equal(np.diff(h.read_first_loc), cnt)
+    # the kernel executes exactly the reference schedule's extension steps
+    d = orc.map_batch(codes, offs, tau, threads=2)
+    assert h.n_ext == d.n_ext
+
+
+@pytest.mark.parametrize("tau", [0, 1, 2])
+def test_map_repeats_matches_reference_dump(workdir, tau):
+    base = common.build_golden_index(workdir, "repeats")
+    ctx = ma.Context.from_files(base, 0)
+    reads = common.load_reads("repeats.reads.txt")
+    codes, offs = common.encode_reads(reads)
+    ref = po.HitDump.load(os.path.join(common.GOLDEN, "repeats.tau%d.bin" % tau))
+    h = ctx.map_batch(codes, offs, tau, want_intervals=True)
+    assert np.array_equal(h.located(), ref.located())
+    assert np.array_equal(h.intervals(), ref.intervals())
+    ctx.close()
+
+
+def test_coordinates_and_strand(small):
+    base, ctx, orc = small
+    reads = common.load_reads("small.reads.txt")
+    codes, offs = common.encode_reads(reads)
+    h = ctx.map_batch(codes, offs, 2)
+    hix = ma.HostIndex.read(base)
+    names = hix.seq_names()
+    for t in range(0, h.n_locs, max(1, h.n_locs // 300)):
+        s = "%s:%d:%s" % (names[h.loc_seq[t]], h.loc_seqpos[t], "-" if h.loc_strand[t] else "+")
+        assert s == orc.pos_to_str(int(h.loc_pos[t])) == hix.pos_to_str(int(h.loc_pos[t]))
+
+
+def test_text_upload_and_encode(small):
+    base, ctx, orc = small
+    reads = common.load_reads("small.reads.txt")
+    codes, offs = common.encode_reads(reads)
+    text = "".join(reads)
+    assert np.array_equal(ctx.encode(text, offs), codes)
+    b = ctx.upload_text(text, offs)
+    b.run(2)
+    h1 = b.fetch()
+    h2 = ctx.map_batch(codes, offs, 2)
+    assert np.array_equal(h1.located(), h2.located())
+    b.close()
+
+
+def test_empty_and_degenerate_batches(small):
+    base, ctx, orc = small
+    h = ctx.map_batch(np.zeros(0, np.uint8), np.zeros(1, np.int64), 2)
+    assert h.n_reads == 0 and h.n_locs == 0
+    codes, offs = common.encode_reads(["", "A", "AC"])
+    h = ctx.map_batch(codes, offs, 2, want_intervals=True)
+    assert h.status.tolist() == [-1, -1, -1] and h.n_locs == 0 and h.n_hits == 0
+    with pytest.raises(ma.GpumapError):
+        ctx.map_batch(codes, offs, ma.MAX_TAU + 1)
+    with pytest.raises(ma.GpumapError):
+        ctx.map_batch(codes, offs, -1)
+
+
+def test_random_batch_matches_oracle(workdir):
+    """Config-2 shaped case at a size the oracle finishes in seconds."""
+    base, seqs = common.synth_index(workdir, "rnd300k", 300_000, seed=21, n_seqs=3)
+    codes, offs = synth.make_reads(seqs, 20000, 100, 2, seed=22)
+    ctx = ma.Context.from_files(base, 0)
+    orc = po.Index(base)
+    h = ctx.map_batch(codes.reshape(-1), offs, 2, want_intervals=True)
+    d = orc.map_batch(codes.reshape(-1), offs, 2, threads=8)
+    assert np.array_equal(h.located(), d.located())
+    assert np.array_equal(h.intervals(), d.intervals())
+    assert h.n_ext == d.n_ext
+    # every read maps back to where it was drawn from: at least one hit with <= 2 mismatches
+    assert (np.diff(h.read_first_loc) >= 1).mean() > 0.99
+    ctx.close()
+
+
+def test_repeat_rich_tau4_matches_oracle(workdir):
+    """Config-5 shaped case (150 nt, tau 4, repeat families, text N)."""
+    base, seqs = common.synth_index(workdir, "rep400k", 400_000, seed=31, n_seqs=2, repeat_rich=True)
+    codes, offs = synth.make_reads(seqs, 3000, 150, 4, seed=32, n_frac=0.02)
+    ctx = ma.Context.from_files(base, 0)
+    orc = po.Index(base)
+    h = ctx.map_batch(codes.reshape(-1), offs, 4, want_intervals=True)
+    d = orc.map_batch(codes.reshape(-1), offs, 4, threads=8)
+    assert np.array_equal(h.located(), d.located())
+    assert np.array_equal(h.intervals(), d.intervals())
+    assert h.n_ext == d.n_ext
+    ctx.close()
+
+
+def test_spill_path_matches_oracle(small):
+    """Reads with many N's blow up the frontier: forces the deque to spill to global memory."""
+    base, ctx, orc = small
+    reads = ["NNNNNNACGTNN", "NNNNNNNN", "ACNNNNNNNNGT"] * 8
+    codes, offs = common.encode_reads(reads)
+    h = ctx.map_batch(codes, offs, 1, want_intervals=True)
+    d = orc.map_batch(codes, offs, 1, threads=4)
+    assert np.array_equal(h.located(), d.located())
+    assert np.array_equal(h.intervals(), d.intervals())
+
+
+def test_sharded_batches_concatenate_in_input_order(workdir):
+    """Logical sharding on one device: contiguous read ranges, concatenated in order."""
+    base, seqs = common.synth_index(workdir, "rnd300k", 300_000, seed=21, n_seqs=3)
+    codes, offs = synth.make_reads(seqs, 4001, 100, 2, seed=23)
+    ctx = ma.Context.from_files(base, 0)
+    whole = ctx.map_batch(codes.reshape(-1), offs, 2).located()
+    for g in (2, 4, 8):
+        parts = []
+        for k in range(g):
+            lo, hi = 4001 * k // g, 4001 * (k + 1) // g
+            loc = ctx.map_batch(codes[lo:hi].reshape(-1), offs[lo:hi + 1] - offs[lo], 2).located()
+            loc[:, 0] += lo
+            parts.append(loc)
+        assert np.array_equal(np.concatenate(parts), whole)
+    ctx.close()
