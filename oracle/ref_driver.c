@@ -84,7 +84,9 @@ static void *map_worker(void *arg)
       char *read = j->reads[r];
       int m = (int)strlen(read);
       j->status[r] = 0;
-      if (m < 1) { j->status[r] = -1; continue; }
+      /* Longer than ALIGN_WORDS*ALIGN_WORD_SIZE (src/blocksearch.h:12-13): aln_bit_set would write
+      ** past spath_t.align (undefined behaviour in the reference), so such reads are not searched. */
+      if (m < 1 || m > 256) { j->status[r] = -1; continue; }
       uint8_t *q = sym_str_index(read, j->index->sym);
       if (q == NULL) { j->rc = -1; break; }
       if (blocksearch_trail_rec(q, 0, m - 1, j->tau + 1, 0, j->index->bwt, tree) == -1) {
