@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the query hot path (block search + locate) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload NAME]
+
+One process per GPU (for N > 1 launched by torch.distributed.run; RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_* come from the environment).  Rank 0 builds the synthetic index on the host, uploads and
+repacks it on its GPU and broadcasts the three device arrays once over xGMI with RCCL
+(torch.distributed, backend "nccl"); every rank then maps its own shard of reads against its own
+replica.  No collective on the data path: reads are independent units (weak scaling: the per-GPU
+batch is fixed, value = reads of all ranks / max-over-ranks time).
+
+A "step" is one pass of the hot path over one batch of reads already resident in HBM:
+gpumap_batch_run = search (k_search) + suffix-array locate + ordering, results left on the device.
+
+One JSON line is printed by rank 0; see DESIGN.md section "Measurement" for the accounting of
+`roofline` (algorithmic bytes = 128 B per extension step of the reference schedule, i.e. two
+64-byte Occ touches) and `cpu_baseline` (the oracle's C restatement on the host
+cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: genome length, sequences, repeat-rich, seed, reads per GPU, read length, tau
+    "plumbing": dict(L=1_000_000, n_seqs=1, rich=False, gc=0.5, seed=1, reads=10_000, m=50, tau=0,
+                     desc="config 1: 1 Mbp random, 10k x 50 nt, exact"),
+    "ecoli": dict(L=4_641_652, n_seqs=1, rich=False, gc=0.508, seed=2, reads=1_000_000, m=100, tau=2,
+                  desc="config 2 stand-in: 4.64 Mbp random (E. coli K-12 size), 1M x 100 nt, <=2 mismatches"),
+    "chr21": dict(L=46_709_983, n_seqs=1, rich=True, gc=0.41, seed=3, reads=10_000_000, m=100, tau=2,
+                  desc="config 3 stand-in: 46.7 Mbp repeat-rich (chr21 size), 10M x 100 nt, <=2 mismatches"),
+}
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+BYTES_PER_EXT = 128.0           # two 64-B Occ touches per extension step
+
+
+class _DevPtr:
+    """Exposes a raw device pointer to torch through __cuda_array_interface__ (no copy)."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False),
+                                         "version": 2}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default=os.environ.get("GPUMAP_WORKLOAD", "chr21"))
+    ap.add_argument("--reads", type=int, default=0, help="reads per GPU (0 = the workload's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--waves-per-cu", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import mapper_amd as ma
+    from mapper_amd import synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "--gpus must equal WORLD_SIZE (launch N>1 with torch.distributed.run)"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    w = dict(WORKLOADS[args.workload])
+    if args.reads:
+        w["reads"] = args.reads
+    t_setup = time.time()
+    # every rank regenerates the same synthetic sequences (deterministic) to draw its reads from
+    seqs, names = synth.make_genome(w["L"], w["seed"], n_seqs=w["n_seqs"], gc=w["gc"], repeat_rich=w["rich"])
+    tmp = tempfile.mkdtemp(prefix="gpumap_bench_")
+    base = os.path.join(tmp, args.workload)
+    keep = []
+    t_index = t_upload = t_bcast = 0.0
+    if rank == 0:
+        t0 = time.time()
+        hix = ma.HostIndex.build_codes(seqs, names, base)       # also writes base.* for the CPU baseline
+        t_index = time.time() - t0
+        t0 = time.time()
+        ctx = ma.Context.from_index(hix, local)
+        t_upload = time.time() - t0
+    if world > 1:
+        # one-off replication of the device-resident index: RCCL broadcast over xGMI
+        t0 = time.time()
+        if rank == 0:
+            dev, hdr = ctx.export()
+            meta = [bytes(hdr), int(dev.occ_bytes), int(dev.sa_bytes), int(dev.tables_bytes)]
+        else:
+            meta = [None, 0, 0, 0]
+        dist.broadcast_object_list(meta, src=0)
+        bufs = []
+        for i, nbytes in enumerate(meta[1:]):
+            if rank == 0:
+                ptr = (dev.occ_blocks, dev.sa_words, dev.tables)[i]
+                t = torch.as_tensor(_DevPtr(ptr, nbytes), device=torch.device("cuda", local))
+            else:
+                t = torch.empty(nbytes, dtype=torch.uint8, device=torch.device("cuda", local))
+            dist.broadcast(t, src=0)
+            bufs.append(t)
+        torch.cuda.synchronize()
+        if rank != 0:
+            d = ma.DevIndex(bufs[0].data_ptr(), meta[1], bufs[1].data_ptr(), meta[2], bufs[2].data_ptr(), meta[3])
+            ctx = ma.Context.from_device(d, meta[0], local, keep=bufs)
+        keep = bufs
+        t_bcast = time.time() - t0
+    if args.waves_per_cu:
+        ctx.set_option("waves_per_cu", args.waves_per_cu)
+
+    # this rank's shard: its own reads (weak scaling), resident in HBM before the timed region
+    codes, offs = synth.make_reads(seqs, w["reads"], w["m"], w["tau"], seed=w["seed"] * 1000 + 17 + rank)
+    batch = ctx.upload(codes.reshape(-1), offs)
+    t_setup = time.time() - t_setup
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        batch.run(w["tau"])
+    barrier()
+    t0 = time.perf_counter()
+    ms_search = []
+    for _ in range(args.steps):
+        c = batch.run(w["tau"])                      # synchronous: returns when the device work is done
+        ms_search.append(c["ms_search"])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    c = batch.counters()
+
+    if rank == 0:
+        total_reads = w["reads"] * world * args.steps
+        value = total_reads / elapsed
+        k_ms = float(np.mean(ms_search))
+        achieved = BYTES_PER_EXT * c["n_ext"] / (k_ms * 1e-3) / 1e9
+        out = {
+            "metric": "reads mapped/sec (node), 100nt <=2 mm; % HBM gather roofline",
+            "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+            "config": {"workload": args.workload, "description": w["desc"], "text_len": int(2 * (w["L"] + w["n_seqs"])),
+                       "reads_per_gpu": w["reads"], "read_len": w["m"], "tau": w["tau"],
+                       "parallelism": "reads sharded over %d GPU(s), index replicated (RCCL broadcast)" % world},
+            "roofline": {"bound": "hbm", "kernel": "k_search", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel_ms": k_ms, "ext_steps_per_launch": c["n_ext"],
+                         "algorithmic_bytes_per_launch": BYTES_PER_EXT * c["n_ext"]},
+            "stages_ms": {"search": c["ms_search"], "locate": c["ms_locate"], "order": c["ms_sort"],
+                          "total": c["ms_total"]},
+            "hits_per_batch": {"intervals": c["n_hits"], "located": c["n_locs"]},
+            "setup_s": {"index_build_host": t_index, "upload_repack": t_upload, "rccl_broadcast": t_bcast,
+                        "all": t_setup},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(base, codes, offs, w, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    batch.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+    del keep
+
+
+def cpu_baseline(base, codes, offs, w, seconds):
+    """The oracle's C restatement (kind "port") on the host cores, on a bounded sample of the same
+    reads against the same index files.  Test infrastructure used as the baseline only."""
+    from oracle import pyoracle as po
+    orc = po.Index(base)
+    cores = min(16, os.cpu_count() or 1)
+    probe = min(len(offs) - 1, 4000 * cores)
+    d = orc.map_batch(codes[:probe].reshape(-1), offs[:probe + 1], w["tau"], threads=cores)
+    rate = probe / max(d.seconds, 1e-6)
+    n = int(min(len(offs) - 1, max(probe, rate * seconds)))
+    d = orc.map_batch(codes[:n].reshape(-1), offs[:n + 1], w["tau"], threads=cores)
+    return {"value": n / d.seconds, "unit": "reads/s", "cores": cores, "kind": "port",
+            "sample": "first %d reads of the batch, %d pthreads, %.1f s" % (n, cores, d.seconds),
+            "ext_steps_per_read": d.n_ext / n}
+
+
+if __name__ == "__main__":
+    main()

@@ -422,8 +422,8 @@ static void *batch_worker(void *arg)
       orc_hit_t *h = NULL;
       int64_t ext = 0;
       int64_t nh = (m >= 1 && m <= 256) ? orc_blocksearch(j->x, j->codes + j->offsets[r], (int)m, j->tau, &h, &ext) : -1;
+      if (nh < 0) { j->status[r] = -1; continue; }   /* steps of a failed search are not counted */
       j->n_ext += ext;
-      if (nh < 0) { j->status[r] = -1; continue; }
       j->status[r] = 0;
       int64_t nl = 0;
       for (int64_t i = 0; i < nh; i++) nl += h[i].sz;
