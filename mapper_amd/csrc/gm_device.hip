@@ -60,7 +60,7 @@ struct gpumap_ctx {
    uint8_t *d_sym_table = nullptr;
    // launch shape
    int cu_count = 256;
-   int waves_per_cu = 8;
+   int waves_per_cu = 12;
    int64_t spill_cap = 16384;         // nodes per wave
    // scratch kept across runs
    DevBuf spill, counters, op_in, op_out, cub_tmp;
@@ -280,7 +280,7 @@ failure_return:
 extern "C" int gpumap_set_option(gpumap_ctx *ctx, const char *name, int64_t value)
 {
    GM_FAIL_IF(ctx == nullptr || name == nullptr, "NULL argument.");
-   if (!strcmp(name, "waves_per_cu")) { GM_FAIL_IF(value < 0 || value > 32, "waves_per_cu out of range."); ctx->waves_per_cu = value ? (int)value : 8; }
+   if (!strcmp(name, "waves_per_cu")) { GM_FAIL_IF(value < 0 || value > 32, "waves_per_cu out of range."); ctx->waves_per_cu = value ? (int)value : 12; }
    else if (!strcmp(name, "spill_nodes")) { GM_FAIL_IF(value < 0 || value > (1 << 22), "spill_nodes out of range."); ctx->spill_cap = value ? ((value + SPILL_CHUNK - 1) / SPILL_CHUNK) * SPILL_CHUNK : 16384; }
    else GM_FAIL("unknown option.");
    return 0;
