@@ -90,6 +90,7 @@ API = {
 API_EXTRA = {
     "gpumap_index_build_codes": (_P, [_P, _P, C.POINTER(C.c_char_p), _I64, C.c_char_p]),
     "gpumap_suffix_sort": (_I, [_P, _I64, _P]),
+    "gpumap_reads_dump": (_I64, [C.c_char_p, C.c_size_t, C.c_char_p]),
 }
 
 _lib = None

@@ -85,3 +85,28 @@ int64_t gm_reads_next(gm_read_stream *s, size_t max_bytes, gm_read_chunk *chunk)
 failure_return:
    return -1;
 }
+
+// Host-only helper: parses `path` exactly as gpumap_mapper does and writes "tag<TAB>letters" lines,
+// with a "#chunk" line between chunks.  Returns the number of reads or -1.  Lets the read pipeline be
+// checked against the reference's io tests (test/test_io.c, test/examples/io_input.*) without a GPU.
+extern "C" int64_t gpumap_reads_dump(const char *path, size_t max_bytes, const char *out_path)
+{
+   gm_read_stream *s = gm_reads_open(path);
+   if (!s) return -1;
+   FILE *fo = fopen(out_path, "w");
+   if (!fo) { gm_reads_close(s); return -1; }
+   gm_read_chunk chunk;
+   int64_t n, total = 0;
+   while ((n = gm_reads_next(s, max_bytes, &chunk)) > 0) {
+      if (total) fprintf(fo, "#chunk\n");
+      for (int64_t i = 0; i < n; i++) {
+         fprintf(fo, "%s\t", chunk.tags[(size_t)i].c_str());
+         fwrite(chunk.text.data() + chunk.offsets[(size_t)i], 1, (size_t)(chunk.offsets[(size_t)i + 1] - chunk.offsets[(size_t)i]), fo);
+         fputc('\n', fo);
+      }
+      total += n;
+   }
+   fclose(fo);
+   gm_reads_close(s);
+   return n < 0 ? -1 : total;
+}

@@ -1,0 +1,210 @@
+"""CPU-only tests of the product's host side: C-ABI surface, index construction and reading, the
+suffix sorter, the read pipeline, argument checking, and the shared kernel core (gm_core.hpp)
+compiled for the host.  No kernel is launched here."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import mapper_amd as ma
+from mapper_amd import synth
+from oracle import pyoracle as po
+from tests import common
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "gpumap.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(gpumap_[a-z_0-9]+)\s*\(", hdr))
+    assert len(declared) >= 25
+    L = C.CDLL(ma.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(L, name), "libgpumap.so does not export %s" % name
+    assert declared == set(ma.API), "python binding and header disagree: %s" % (declared ^ set(ma.API))
+    assert b"gfx950" in ma.lib().gpumap_version()
+
+
+def test_library_contains_gfx950_code_object():
+    blob = open(ma.LIB_PATH, "rb").read()
+    assert b"amdgcn-amd-amdhsa--gfx950" in blob and b"k_search" in blob
+
+
+def test_null_arguments_follow_error_convention(capfd):
+    L = ma.lib()
+    assert not L.gpumap_index_read(None)
+    assert not L.gpumap_index_build(None, b"x")
+    assert not L.gpumap_create(None, 0)
+    assert L.gpumap_index_view_of(None, None) == -1
+    assert L.gpumap_occ_all(None, 1, None, None) == -1
+    assert L.gpumap_map_batch(None, None, None, 0, 0, 0, None) == -1
+    assert L.gpumap_batch_run(None, None, 0, 0) == -1
+    assert L.gpumap_mapper(None, None, None, 0, None) == -1
+    err = capfd.readouterr().err
+    # func \t (file:line) error: msg   (src/errhandler.c:12-15)
+    assert re.search(r"gpumap_index_read\t\(.*gm_index\.cpp:\d+\) error: argument 'filename_base' is NULL\.", err)
+    assert not L.gpumap_index_read(b"/nonexistent/base")
+
+
+def test_index_read_roundtrip_and_view(workdir):
+    base = common.build_golden_index(workdir, "small")
+    ix = ma.HostIndex.read(base)
+    orc = po.Index(base)
+    v = ix.view
+    assert v.txt_len == orc.txt_len and v.sar_bits == orc.sar_bits and v.seq_cnt == 2 and v.rc_flag == 1
+    assert v.wil_cnt == 4 and v.occ_mark_intv == 14 and v.occ_word_size == 64 and v.sym_count == 5
+    assert ix.seq_names() == ["seqA", "seqB"]                # name stops at the first space (src/index.c:295-297)
+    assert [int(C.cast(v.c, C.POINTER(C.c_uint64))[i]) for i in range(6)] == orc.c
+    n = v.txt_len
+    text = np.ctypeslib.as_array(C.cast(v.text, C.POINTER(C.c_uint8)), shape=(n,))
+    comp = np.array([3, 2, 1, 0, 4, 5], dtype=np.uint8)
+    # F $ revcomp(F) $  (src/index_txt.c:314-334)
+    assert text[n // 2 - 1] == 5 and text[n - 1] == 5
+    assert np.array_equal(text[n // 2:n - 1], comp[text[:n // 2 - 1][::-1]])
+    for p in (0, 5, n // 2 - 2, n // 2, n - 2):
+        assert ix.pos_to_str(p) == orc.pos_to_str(p)
+    with pytest.raises(ma.GpumapError):
+        ix.pos_to_str(n)
+
+
+def test_fasta_quirks_match_reference_rules(workdir):
+    fa = os.path.join(workdir, "quirks.fa")
+    with open(fa, "w") as f:
+        f.write(">  s1   desc\nACGTxacgt\n\nNNAC\n>s2\nTTTT")      # no trailing newline, blank line, junk letters
+    ix = ma.HostIndex.build(fa, os.path.join(workdir, "quirks"))
+    assert ix.seq_names() == ["s1", "s2"]
+    v = ix.view
+    text = np.ctypeslib.as_array(C.cast(v.text, C.POINTER(C.c_uint8)), shape=(v.txt_len,))
+    assert text[:v.txt_len // 2].tolist() == [0, 1, 2, 3, 4, 0, 1, 2, 3, 4, 4, 0, 1, 5, 3, 3, 3, 3, 5]
+    # duplicate names and a file that does not start with '>' are errors
+    with open(fa, "w") as f:
+        f.write(">a\nAC\n>a\nGT\n")
+    with pytest.raises(ma.GpumapError):
+        ma.HostIndex.build(fa, os.path.join(workdir, "dup"))
+    with open(fa, "w") as f:
+        f.write("ACGT\n")
+    with pytest.raises(ma.GpumapError):
+        ma.HostIndex.build(fa, os.path.join(workdir, "nohdr"))
+
+
+def _sa(text):
+    codes = np.array([{"A": 0, "C": 1, "G": 2, "T": 3, "$": 5}.get(c.upper(), 4) for c in text], dtype=np.uint8)
+    out = np.empty(len(codes), dtype=np.int64)
+    assert ma.lib().gpumap_suffix_sort(codes.ctypes.data_as(C.c_void_p), len(codes), out.ctypes.data_as(C.c_void_p)) == 0
+    return out.tolist()
+
+
+def test_suffix_sorter_known_answers():
+    # test/test_index_sar.c:8-17 (texts with N, junk letters and several separators)
+    assert _sa("TAGCNTCGACA$") == [11, 10, 8, 1, 9, 6, 3, 7, 2, 0, 5, 4]
+    assert _sa("TGNGA$TCGAT$") == [11, 5, 4, 9, 7, 3, 8, 1, 10, 6, 0, 2]
+    assert _sa("AAaaAAaaA$") == [9, 8, 7, 6, 5, 4, 3, 2, 1, 0]
+    assert _sa("acgTPGaKcnN$") == [11, 0, 6, 1, 8, 5, 2, 3, 10, 7, 4, 9]
+    assert _sa("$TgAgcatGGC$acTCGA$") == [18, 11, 0, 17, 12, 3, 6, 10, 5, 15, 13, 16, 2, 9, 4, 8, 14, 1, 7]
+    # :105-126 a 10 000-symbol periodic text
+    sa = _sa("TGCAAAAAA$" * 1000)
+    for k in range(10):
+        assert sa[1000 * k:1000 * (k + 1)] == [9999 - k - 10 * i for i in range(1000)]
+
+
+def test_suffix_sorter_random_against_naive():
+    rng = np.random.default_rng(3)
+    for n in (1, 2, 50, 700):
+        t = "".join(rng.choice(list("ACGTN$AC"), n))
+        naive = sorted(range(n), key=lambda i: [("$ACGTN".index(c)) for c in t[i:]])
+        assert _sa(t) == naive
+
+
+def test_read_pipeline_matches_reference_io_tests(workdir):
+    """test/test_io.c:70-190 on the reference's own example files."""
+    def dump(name, buf):
+        out = os.path.join(workdir, name + ".dump")
+        n = ma.lib().gpumap_reads_dump(os.path.join(common.GOLDEN, name).encode(), buf, out.encode())
+        return n, [c.strip("\n").split("\n") for c in open(out).read().split("#chunk\n")]
+    n, chunks = dump("io_input.raw", 1 << 20)
+    assert n == 6 and len(chunks) == 1
+    assert chunks[0][3:] == ["4\tACGTACATGTATGACAC", "5\tNNNNNNNNACGTACGCC", "6\tNNNNNNLLYYYYJDFLS"]
+    n, chunks = dump("io_input.fasta", 80)
+    assert n == 6 and [len(c) for c in chunks] == [4, 2]
+    assert chunks[0][0] == "seq1\tATGCGTACGTCGTATCA" and chunks[1] == ["seq5\tNNNNNNNNACGTACGCC", "seq6\tNNNNNNLLYYYYJDFLS"]
+    n, chunks = dump("io_input.fastq", 50)
+    assert n == 6 and [len(c) for c in chunks] == [2, 2, 2]
+    assert chunks[0] == ["seq1\tATGCGTACGTCGTATCA", "seq2\tGTATCGACTACGAGCTA"]
+    # inconsistent quality length is an error (src/seqread.c:47-49)
+    bad = os.path.join(workdir, "bad.fastq")
+    open(bad, "w").write("@r\nACGT\n+\nIII\n")
+    assert ma.lib().gpumap_reads_dump(bad.encode(), 1 << 20, (bad + ".dump").encode()) == -1
+    assert ma.lib().gpumap_reads_dump(b"/nonexistent", 10, b"/tmp/x") == -1
+
+
+# ---------------------------------------------------------------- shared kernel core on the host
+
+@pytest.fixture(scope="module")
+def emu():
+    path = os.path.join(ROOT, "tests", "hostemu", "_build", "libhostemu.so")
+    if not os.path.exists(path):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "hostemu")])
+    E = C.CDLL(path)
+    E.emu_create.restype = C.c_void_p
+    E.emu_create.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
+    E.emu_search.restype = C.c_int64
+    E.emu_search.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.POINTER(C.c_int64))]
+    E.emu_occ_all.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+    E.emu_free.argtypes = [C.c_void_p]
+    E.emu_destroy.argtypes = [C.c_void_p]
+    return E
+
+
+def test_kernel_core_block_layout_and_schedule_on_host(emu, workdir):
+    """gm_core.hpp (rank blocks, node packing, phase table, per-node step), run sequentially on the
+    host, gives the oracle's ranks, hits and extension-step counts."""
+    base = common.build_golden_index(workdir, "small")
+    hix = ma.HostIndex.read(base)
+    v = hix.view
+    h = emu.emu_create(v.occ, v.occ_mark_intv, v.c, v.txt_len)
+    orc = po.Index(base)
+    rng = np.random.default_rng(5)
+    for p in [-1, 0, 126, 127, 128, v.txt_len - 1] + rng.integers(-1, v.txt_len, 3000).tolist():
+        out = (C.c_int64 * 5)()
+        emu.emu_occ_all(h, int(p), out)
+        assert list(out) == orc.occ_all(int(p))
+    reads = common.load_reads("small.reads.txt")
+    for tau in (0, 1, 2, 4, 7):
+        for r in reads[::7] + reads[-20:]:
+            if not r or len(r) > 256:
+                continue
+            q = orc.encode(r)
+            hp = C.POINTER(po.OrcHit)()
+            ne = C.c_int64()
+            nref = po.lib().orc_blocksearch(orc._h, q.ctypes.data_as(C.POINTER(C.c_uint8)), len(q), tau, C.byref(hp), C.byref(ne))
+            op = C.POINTER(C.c_int64)()
+            n = emu.emu_search(h, q.ctypes.data_as(C.c_void_p), len(q), tau, C.byref(op))
+            if nref < 0:
+                assert n == -1
+                continue
+            mine = sorted(tuple(int(op[10 * i + k]) for k in range(9)) for i in range(n))
+            want = sorted((x.fp, x.rp, x.sz, x.dp, x.score) + tuple(int(np.int64(np.uint64(a))) for a in x.align)
+                          for x in (hp[i] for i in range(nref)))
+            assert mine == want
+            assert (int(op[9]) if n > 0 else int(op[0])) == ne.value
+            emu.emu_free(op)
+            po.lib()._libc.free(C.cast(hp, C.c_void_p))
+    emu.emu_destroy(h)
+
+
+def test_synthetic_generators_are_deterministic():
+    a, _ = synth.make_genome(50_000, seed=9, n_seqs=3, repeat_rich=True)
+    b, _ = synth.make_genome(50_000, seed=9, n_seqs=3, repeat_rich=True)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b)) and sum(len(x) for x in a) == 50_000
+    r1, o1 = synth.make_reads(a, 500, 60, 3, seed=4)
+    r2, o2 = synth.make_reads(b, 500, 60, 3, seed=4)
+    assert np.array_equal(r1, r2) and np.array_equal(o1, o2) and r1.shape == (500, 60)
+    assert (r1 == 4).sum(axis=1).max() <= 1                  # no read is drawn from an N run
+    s = synth.Stream(1)
+    x = s.u64(10)
+    s2 = synth.Stream(1)
+    assert np.array_equal(np.concatenate([s2.u64(4), s2.u64(6)]), x)   # chunked == whole
