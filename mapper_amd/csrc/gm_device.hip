@@ -9,6 +9,7 @@
 #include <vector>
 #include "gm_host.hpp"
 #include "gm_kernels.hpp"
+#include "gm_search_lane.hpp"
 
 using namespace gm;
 
@@ -60,7 +61,8 @@ struct gpumap_ctx {
    uint8_t *d_sym_table = nullptr;
    // launch shape
    int cu_count = 256;
-   int waves_per_cu = 12;
+   int waves_per_cu = 0;              // 0 = the variant's default
+   int variant = 1;                   // 0 = k_search (node per quad), 1 = k_search_lane (node per lane)
    int64_t spill_cap = 16384;         // nodes per wave
    // scratch kept across runs
    DevBuf spill, counters, op_in, op_out, cub_tmp;
@@ -107,6 +109,7 @@ static int ctx_common_init(gpumap_ctx *ctx, int device)
    HIP_TRY(hipMalloc((void **)&ctx->d_sym_table, 256));
    HIP_TRY(hipMemcpy(ctx->d_sym_table, ctx->sym_table, 256, hipMemcpyHostToDevice));
    HIP_TRY(ctx->counters.ensure(64));
+   if (const char *e = getenv("GPUMAP_SEARCH_VARIANT")) ctx->variant = atoi(e) == 0 ? 0 : 1;   // tuning aid
    return 0;
 failure_return:
    return -1;
@@ -280,7 +283,8 @@ failure_return:
 extern "C" int gpumap_set_option(gpumap_ctx *ctx, const char *name, int64_t value)
 {
    GM_FAIL_IF(ctx == nullptr || name == nullptr, "NULL argument.");
-   if (!strcmp(name, "waves_per_cu")) { GM_FAIL_IF(value < 0 || value > 32, "waves_per_cu out of range."); ctx->waves_per_cu = value ? (int)value : 12; }
+   if (!strcmp(name, "waves_per_cu")) { GM_FAIL_IF(value < 0 || value > 32, "waves_per_cu out of range."); ctx->waves_per_cu = (int)value; }
+   else if (!strcmp(name, "search_variant")) { GM_FAIL_IF(value < 0 || value > 1, "search_variant out of range."); ctx->variant = (int)value; }
    else if (!strcmp(name, "spill_nodes")) { GM_FAIL_IF(value < 0 || value > (1 << 22), "spill_nodes out of range."); ctx->spill_cap = value ? ((value + SPILL_CHUNK - 1) / SPILL_CHUNK) * SPILL_CHUNK : 16384; }
    else GM_FAIL("unknown option.");
    return 0;
@@ -509,7 +513,8 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
       HIP_TRY(hipStreamSynchronize(st));          // the staging vectors above go out of scope
 
       // ---- K2 search (rerun once with an exact buffer if the hit list overflowed)
-      const int n_wg = std::max(1, ctx->cu_count * ctx->waves_per_cu / WG_WAVES);
+      const int wpc = ctx->waves_per_cu ? ctx->waves_per_cu : (ctx->variant == 1 ? 8 : 12);
+      const int n_wg = std::max(1, ctx->cu_count * wpc / WG_WAVES);
       const int64_t n_waves = (int64_t)n_wg * WG_WAVES;
       HIP_TRY(ctx->spill.ensure((size_t)n_waves * (size_t)ctx->spill_cap * sizeof(Node)));
       unsigned long long *cnt = ctx->counters.as<unsigned long long>();   // [0] cursor [1] hits [2] n_ext [3] error
@@ -528,7 +533,10 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
          A.cursor = cnt + 0; A.hits = b->hits.as<Node>(); A.hit_cap = hit_cap; A.hit_count = cnt + 1; A.n_ext = cnt + 2;
          A.spill = ctx->spill.as<Node>(); A.spill_cap = (uint32_t)ctx->spill_cap; A.error = (int *)(cnt + 3);
          if (R > 0) {
-            hipLaunchKernelGGL(k_search, dim3((unsigned)n_wg), dim3(WG_THREADS), 0, st, A);
+            if (ctx->variant == 1)
+               hipLaunchKernelGGL(k_search_lane, dim3((unsigned)n_wg), dim3(WG_THREADS), (size_t)ctx->ix.n_super * SYMS * 8, st, A);
+            else
+               hipLaunchKernelGGL(k_search, dim3((unsigned)n_wg), dim3(WG_THREADS), 0, st, A);
             HIP_TRY(hipGetLastError());
          }
          HIP_TRY(hipMemcpyAsync(host_cnt, cnt, 32, hipMemcpyDeviceToHost, st));

@@ -228,27 +228,32 @@ __device__ __forceinline__ uint32_t quad_sum(uint32_t x)
    return x;
 }
 
+// Selection by a per-lane index, written over values (not over the array) so that the arrays stay
+// in registers: a select chain over array elements is turned into an indexed stack access.
 template <class T>
-__device__ __forceinline__ T sel5(const T v[SYMS], int j)
+__device__ __forceinline__ T sel5v(T v0, T v1, T v2, T v3, T v4, int j)
 {
-   T r = v[0];
-   r = j == 1 ? v[1] : r;
-   r = j == 2 ? v[2] : r;
-   r = j == 3 ? v[3] : r;
-   r = j == 4 ? v[4] : r;
+   T r = v0;
+   r = j == 1 ? v1 : r;
+   r = j == 2 ? v2 : r;
+   r = j == 3 ? v3 : r;
+   r = j == 4 ? v4 : r;
    return r;
 }
+#define sel5(v, j) sel5v((v)[0], (v)[1], (v)[2], (v)[3], (v)[4], (j))
 
+template <int CAP = QCAP>
 __device__ __forceinline__ void lds_store_node(Node *q, uint32_t slot, const Node &nd)
 {
-   uint4 *d = reinterpret_cast<uint4 *>(q + (slot & (QCAP - 1)));
+   uint4 *d = reinterpret_cast<uint4 *>(q + (slot & (CAP - 1)));
    d[0] = make_uint4(nd.w[0], nd.w[1], nd.w[2], nd.w[3]);
    d[1] = make_uint4(nd.w[4], nd.w[5], nd.w[6], nd.w[7]);
 }
 
+template <int CAP = QCAP>
 __device__ __forceinline__ void lds_load_node(const Node *q, uint32_t slot, Node &nd)
 {
-   const uint4 *s = reinterpret_cast<const uint4 *>(q + (slot & (QCAP - 1)));
+   const uint4 *s = reinterpret_cast<const uint4 *>(q + (slot & (CAP - 1)));
    uint4 a = s[0], b = s[1];
    nd.w[0] = a.x; nd.w[1] = a.y; nd.w[2] = a.z; nd.w[3] = a.w;
    nd.w[4] = b.x; nd.w[5] = b.y; nd.w[6] = b.z; nd.w[7] = b.w;
@@ -268,28 +273,29 @@ struct WaveQueue {
 };
 
 // Converged call: every lane of the wave executes it.  Lanes with `flag` append `nd`.
+template <int CAP = QCAP, int CHUNK = SPILL_CHUNK>
 __device__ __forceinline__ void wave_push(WaveQueue &wq, bool flag, const Node &nd, int lane)
 {
-   if (wq.top - wq.bot + 64 > QCAP) {
-      // Spill the oldest SPILL_CHUNK nodes (LIFO order is kept: they return only when the deque is empty).
-      bool room = wq.spill_top + SPILL_CHUNK <= wq.spill_cap;
+   if (wq.top - wq.bot + 64 > CAP) {
+      // Spill the oldest CHUNK nodes (LIFO order is kept: they return only when the deque is empty).
+      bool room = wq.spill_top + CHUNK <= wq.spill_cap;
       if (room) {
-         for (int i = lane; i < SPILL_CHUNK; i += 64) {
+         for (int i = lane; i < CHUNK; i += 64) {
             Node t;
-            lds_load_node(wq.q, wq.bot + i, t);
+            lds_load_node<CAP>(wq.q, wq.bot + i, t);
             uint4 *d = reinterpret_cast<uint4 *>(wq.spill + wq.spill_top + i);
             d[0] = make_uint4(t.w[0], t.w[1], t.w[2], t.w[3]);
             d[1] = make_uint4(t.w[4], t.w[5], t.w[6], t.w[7]);
          }
-         wq.spill_top += SPILL_CHUNK;
+         wq.spill_top += CHUNK;
       } else if (lane == 0) {
          *wq.error = 1;      // results are incomplete; the host reports the failure
       }
-      wq.bot += SPILL_CHUNK;
+      wq.bot += CHUNK;
       wave_sync();
    }
    unsigned long long m = __ballot(flag);
-   if (flag) lds_store_node(wq.q, wq.top + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), nd);
+   if (flag) lds_store_node<CAP>(wq.q, wq.top + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), nd);
    wq.top += (uint32_t)__popcll(m);
 }
 
