@@ -170,6 +170,8 @@ def main():
             "stages_ms": {"search": c["ms_search"], "locate": c["ms_locate"], "order": c["ms_sort"],
                           "total": c["ms_total"]},
             "hits_per_batch": {"intervals": c["n_hits"], "located": c["n_locs"]},
+            "occupancy": {"loop_passes": c["loop_passes"], "child_passes": c["child_passes"],
+                          "lane_fill": (c["n_ext"] / (64.0 * c["loop_passes"])) if c["loop_passes"] else None},
             "setup_s": {"index_build_host": t_index, "upload_repack": t_upload, "rccl_broadcast": t_bcast,
                         "all": t_setup},
         }

@@ -183,6 +183,10 @@ int           gpumap_batch_fetch(gpumap_ctx *ctx, gpumap_batch *batch, gpumap_hi
 /* Counters of the last run without copying hits: n_hits, n_locs, n_ext, and stage times (ms). */
 int           gpumap_batch_counters(const gpumap_batch *batch, int64_t *n_hits, int64_t *n_locs,
                                     int64_t *n_ext, float ms[4]);
+/* Occupancy figures of the last search (tuning aid; no counterpart in the reference):
+** stats[0] = passes of the search loop summed over all wavefronts (n_ext / (64 * stats[0]) = share
+** of lanes that held a node), stats[1] = passes of the inner loop over children, [2..3] reserved. */
+int           gpumap_batch_stats(const gpumap_batch *batch, int64_t stats[4]);
 void          gpumap_batch_free(gpumap_batch *batch);
 
 /* ------------------------------------------------------------------------------------------

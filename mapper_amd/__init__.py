@@ -81,6 +81,7 @@ API = {
     "gpumap_batch_run": (_I, [_P, _P, _I, _I]),
     "gpumap_batch_fetch": (_I, [_P, _P, C.POINTER(_Hits)]),
     "gpumap_batch_counters": (_I, [_P, C.POINTER(_I64), C.POINTER(_I64), C.POINTER(_I64), C.POINTER(C.c_float)]),
+    "gpumap_batch_stats": (_I, [_P, C.POINTER(_I64)]),
     "gpumap_batch_free": (None, [_P]),
     "gpumap_mapper": (_I, [C.c_char_p, _P, _P, _I, C.c_char_p]),
     "gpumap_set_option": (_I, [_P, C.c_char_p, _I64]),
@@ -223,8 +224,11 @@ class Batch:
         ms = (C.c_float * 4)()
         if lib().gpumap_batch_counters(self._h, C.byref(nh), C.byref(nl), C.byref(ne), ms) != 0:
             raise GpumapError("gpumap_batch_counters failed")
+        st = (_I64 * 4)()
+        if lib().gpumap_batch_stats(self._h, st) != 0:
+            raise GpumapError("gpumap_batch_stats failed")
         return dict(n_hits=nh.value, n_locs=nl.value, n_ext=ne.value, ms_search=ms[0], ms_locate=ms[1],
-                    ms_sort=ms[2], ms_total=ms[3])
+                    ms_sort=ms[2], ms_total=ms[3], loop_passes=st[0], child_passes=st[1])
 
     def fetch(self):
         raw = _Hits()

@@ -79,6 +79,7 @@ struct gpumap_batch {
    DevBuf hkeys, hkeys_alt, hidx, hidx_alt, hit_read, hit_fp, hit_rp, hit_sz, hit_dp, hit_score, hit_align;
    bool length_seen[MAX_READ + 1];
    int64_t n_hits = 0, n_locs = 0, n_ext = 0;
+   int64_t stats[4] = {0, 0, 0, 0};
    bool have_intervals = false, ran = false;
    int tau = 0;
    float ms[4] = {0, 0, 0, 0};
@@ -518,7 +519,7 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
       const int64_t n_waves = (int64_t)n_wg * WG_WAVES;
       HIP_TRY(ctx->spill.ensure((size_t)n_waves * (size_t)ctx->spill_cap * sizeof(Node)));
       unsigned long long *cnt = ctx->counters.as<unsigned long long>();   // [0] cursor [1] hits [2] n_ext [3] error
-      unsigned long long host_cnt[4] = {0, 0, 0, 0};
+      unsigned long long host_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       size_t hit_cap = std::max<size_t>((size_t)1 << 16, (size_t)R * 2);
       HIP_TRY(hipEventRecord(b->ev[0], st));
       for (int attempt = 0; attempt < 2; attempt++) {
@@ -531,7 +532,7 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
          A.len_row = b->len_row.as<const uint8_t>(); A.phases = b->phases.as<const uint32_t>();
          A.n_reads = R; A.stride = b->stride; A.tau = tau;
          A.cursor = cnt + 0; A.hits = b->hits.as<Node>(); A.hit_cap = hit_cap; A.hit_count = cnt + 1; A.n_ext = cnt + 2;
-         A.spill = ctx->spill.as<Node>(); A.spill_cap = (uint32_t)ctx->spill_cap; A.error = (int *)(cnt + 3);
+         A.spill = ctx->spill.as<Node>(); A.spill_cap = (uint32_t)ctx->spill_cap; A.error = (int *)(cnt + 3); A.stats = cnt + 4;
          if (R > 0) {
             if (ctx->variant == 1)
                hipLaunchKernelGGL(k_search_lane, dim3((unsigned)n_wg), dim3(WG_THREADS), (size_t)ctx->ix.n_super * SYMS * 8, st, A);
@@ -539,7 +540,7 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
                hipLaunchKernelGGL(k_search, dim3((unsigned)n_wg), dim3(WG_THREADS), 0, st, A);
             HIP_TRY(hipGetLastError());
          }
-         HIP_TRY(hipMemcpyAsync(host_cnt, cnt, 32, hipMemcpyDeviceToHost, st));
+         HIP_TRY(hipMemcpyAsync(host_cnt, cnt, 64, hipMemcpyDeviceToHost, st));
          HIP_TRY(hipStreamSynchronize(st));
          GM_FAIL_IF(host_cnt[3] != 0, "search spill region overflowed (raise 'spill_nodes').");
          if (host_cnt[1] <= hit_cap) break;
@@ -549,6 +550,7 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
       HIP_TRY(hipEventRecord(b->ev[1], st));
       b->n_hits = (int64_t)host_cnt[1];
       b->n_ext = (int64_t)host_cnt[2];
+      for (int i = 0; i < 4; i++) b->stats[i] = (int64_t)host_cnt[4 + i];
 
       // ---- K3 locate: sizes -> scan -> flat gather
       const int64_t H = b->n_hits;
@@ -648,6 +650,16 @@ extern "C" int gpumap_batch_counters(const gpumap_batch *b, int64_t *n_hits, int
    if (n_locs) *n_locs = b->n_locs;
    if (n_ext) *n_ext = b->n_ext;
    if (ms) for (int i = 0; i < 4; i++) ms[i] = b->ms[i];
+   return 0;
+failure_return:
+   return -1;
+}
+
+extern "C" int gpumap_batch_stats(const gpumap_batch *b, int64_t stats[4])
+{
+   GM_FAIL_IF(b == nullptr || stats == nullptr, "NULL argument.");
+   GM_FAIL_IF(!b->ran, "batch has not been run.");
+   for (int i = 0; i < 4; i++) stats[i] = b->stats[i];
    return 0;
 failure_return:
    return -1;

@@ -219,6 +219,7 @@ struct SearchArgs {
    Node *spill;                 // [waves][spill_cap]
    uint32_t spill_cap;
    int *error;                  // set to 1 when a spill region overflows
+   unsigned long long *stats;   // [0] passes of the main loop over all waves, [1] passes of the child loop
 };
 
 __device__ __forceinline__ uint32_t quad_sum(uint32_t x)

@@ -21,6 +21,42 @@ namespace gm {
 constexpr int LQCAP = 128;           // deque capacity per wave (nodes), power of two
 constexpr int LCHUNK = 64;           // nodes moved per spill / reload
 constexpr int STAGE_SLOT_U4 = 5;     // staging slot per lane, in 16-byte units (4 used + 1 pad)
+constexpr int HITBUF = 128;          // finished nodes staged per wave before they go to the global list
+
+// Finished nodes are staged in a per-wave LDS ring and leave it 64 at a time: one atomic on the
+// global counter and one contiguous 2-KB store per 64 hits.  (One atomic per emitting pass, as in
+// k_search, serialises all waves on one address: about 10 ns per atomic, the whole kernel time.)
+struct HitRing {
+   Node *ring;
+   uint32_t head, tail;
+};
+
+__device__ __forceinline__ void hit_flush(const SearchArgs &A, HitRing &hr, int lane, uint32_t n)
+{
+   unsigned long long base = 0;
+   if (lane == 0) base = atomicAdd(A.hit_count, (unsigned long long)n);
+   base = __shfl(base, 0);
+   if ((uint32_t)lane < n && base + lane < A.hit_cap) {
+      Node t;
+      lds_load_node<HITBUF>(hr.ring, hr.head + lane, t);
+      uint4 *d = reinterpret_cast<uint4 *>(A.hits + base + lane);
+      d[0] = make_uint4(t.w[0], t.w[1], t.w[2], t.w[3]);
+      d[1] = make_uint4(t.w[4], t.w[5], t.w[6], t.w[7]);
+   }
+   hr.head += n;
+   wave_sync();
+}
+
+// Converged call: lanes with `flag` append `nd`.
+__device__ __forceinline__ void hit_emit(const SearchArgs &A, HitRing &hr, bool flag, const Node &nd, int lane)
+{
+   unsigned long long m = __ballot(flag);
+   if (m == 0) return;
+   if (flag) lds_store_node<HITBUF>(hr.ring, hr.tail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), nd);
+   hr.tail += (uint32_t)__popcll(m);
+   wave_sync();
+   if (hr.tail - hr.head >= 64) hit_flush(A, hr, lane, 64);
+}
 
 // Broadcast of lane i's value to its quad (DPP quad_perm [i,i,i,i]); every lane must be active.
 template <int I>
@@ -58,6 +94,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_search_lane(SearchArgs A)
 {
    __shared__ Node s_q[WG_WAVES][LQCAP];
    __shared__ uint4 s_stage[WG_WAVES][64 * STAGE_SLOT_U4];
+   __shared__ Node s_hit[WG_WAVES][HITBUF];
    extern __shared__ unsigned long long s_cb[];              // C[j] + count of j before superblock s
 
    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, sub = lane & 3;
@@ -73,6 +110,10 @@ __global__ void __launch_bounds__(WG_THREADS) k_search_lane(SearchArgs A)
    wq.spill_cap = A.spill_cap;
    wq.error = A.error;
    uint4 *stage = s_stage[wid];
+   HitRing hr;
+   hr.ring = s_hit[wid];
+   hr.head = hr.tail = 0;
+   unsigned long long n_iter = 0, n_child_iter = 0;
 
    const int seeds_per = A.tau + 1;
    const int reads_per_refill = 64 / seeds_per;
@@ -158,6 +199,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_search_lane(SearchArgs A)
          continue;
       }
       ext_count += (unsigned long long)__popcll(__ballot(have));
+      n_iter++;
 
       // ------------------------------------------------------------ fetch: all loads first, then the hand-over
       const int64_t a = cur.fw ? cur.rp : cur.fp, other = cur.fw ? cur.fp : cur.rp;
@@ -218,6 +260,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_search_lane(SearchArgs A)
       NodeR next = cur;
       bool kept = false;
       while (__any(cand != 0)) {
+         n_child_iter++;
          bool push = false, emit = false;
          Node out;
          for (int k = 0; k < 8; k++) out.w[k] = 0;
@@ -240,7 +283,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_search_lane(SearchArgs A)
             }
          }
          if (__any(push)) wave_push<LQCAP, LCHUNK>(wq, push, out, lane);
-         wave_emit(A, emit, out, lane);
+         hit_emit(A, hr, emit, out, lane);
       }
       if (have) {
          cur = next;
@@ -248,7 +291,12 @@ __global__ void __launch_bounds__(WG_THREADS) k_search_lane(SearchArgs A)
       }
       wave_sync();
    }
-   if (lane == 0 && ext_count) atomicAdd(A.n_ext, ext_count);
+   if (hr.tail != hr.head) hit_flush(A, hr, lane, hr.tail - hr.head);
+   if (lane == 0 && ext_count) {
+      atomicAdd(A.n_ext, ext_count);
+      atomicAdd(A.stats + 0, n_iter);
+      atomicAdd(A.stats + 1, n_child_iter);
+   }
 }
 
 }  // namespace gm
