@@ -144,7 +144,8 @@ GM_HD void pack_block(const uint64_t *ref_occ, int64_t mark_intv, int64_t n_ref_
 //
 //   w0 fp[31:0]  w1 rp[31:0]  w2 sz[31:0]  w3 fp[39:32] | rp[39:32]<<8 | sz[39:32]<<16 | pos<<24
 //   w4 read index
-//   w5 phase(6) | dash(1)<<6 | score(4)<<7 | sref(4)<<11 | fw(1)<<15 | end(8)<<16 | tau(4)<<24 | diff(4)<<28
+//   w5 phase(6) | dash(1)<<6 | score(3)<<7 | sref(3)<<10 | fw(1)<<13 | end(8)<<14 | tau(3)<<22 | diff(3)<<25 |
+//      first(3)<<28: a node pushed back as a continuation resumes with the candidate symbols >= first
 //   w6,w7 mismatch positions, one byte each, in the order found (at most 7); byte 7 of the pair
 //         holds (read length - 1)
 // A finished node (hit) is stored in the same format (pos field unused).
@@ -158,15 +159,20 @@ struct NodeR {      // unpacked, in registers
    uint32_t read;
    uint64_t mm;     // mismatch positions + (m-1) << 56
    int pos, end, phase, score, sref, tau, diff;
+   int first = 0;   // first candidate symbol still to be followed (continuations of k_search_lane)
    bool dash, fw;
 };
+
+constexpr int META_DASH = 6, META_SCORE = 7, META_SREF = 10, META_FW = 13, META_END = 14, META_TAU = 22,
+              META_DIFF = 25, META_FIRST = 28;
 
 constexpr int PHASE_FINAL = 63;
 
 GM_HD uint32_t pack_meta(const NodeR &n)
 {
-   return (uint32_t)n.phase | ((uint32_t)n.dash << 6) | ((uint32_t)n.score << 7) | ((uint32_t)n.sref << 11) |
-          ((uint32_t)n.fw << 15) | ((uint32_t)n.end << 16) | ((uint32_t)n.tau << 24) | ((uint32_t)n.diff << 28);
+   return (uint32_t)n.phase | ((uint32_t)n.dash << META_DASH) | ((uint32_t)n.score << META_SCORE) |
+          ((uint32_t)n.sref << META_SREF) | ((uint32_t)n.fw << META_FW) | ((uint32_t)n.end << META_END) |
+          ((uint32_t)n.tau << META_TAU) | ((uint32_t)n.diff << META_DIFF) | ((uint32_t)n.first << META_FIRST);
 }
 
 GM_HD void pack_node(const NodeR &n, Node &o)
@@ -187,8 +193,9 @@ GM_HD void unpack_node(const Node &i, NodeR &n)
    n.pos = (int)(i.w[3] >> 24);
    n.read = i.w[4];
    uint32_t m = i.w[5];
-   n.phase = m & 63; n.dash = (m >> 6) & 1; n.score = (m >> 7) & 15; n.sref = (m >> 11) & 15;
-   n.fw = (m >> 15) & 1; n.end = (m >> 16) & 255; n.tau = (m >> 24) & 15; n.diff = (m >> 28) & 15;
+   n.phase = m & 63; n.dash = (m >> META_DASH) & 1; n.score = (m >> META_SCORE) & 7; n.sref = (m >> META_SREF) & 7;
+   n.fw = (m >> META_FW) & 1; n.end = (m >> META_END) & 255; n.tau = (m >> META_TAU) & 7; n.diff = (m >> META_DIFF) & 7;
+   n.first = (m >> META_FIRST) & 7;
    n.mm = (uint64_t)i.w[6] | ((uint64_t)i.w[7] << 32);
 }
 
@@ -310,11 +317,59 @@ GM_HD int make_child(const NodeR &cur, int nt, int qc, int64_t cfp, int64_t crp,
       }
    }
    child = cur;
+   child.first = 0;
    child.fp = cfp; child.rp = crp; child.sz = csz;
    child.score = s; child.dash = dash; child.mm = mm;
    if (cur.pos == cur.end) return CHILD_DONE;
    child.pos = cur.fw ? cur.pos + 1 : cur.pos - 1;
    return CHILD_NODE;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same rules on the packed meta word (k_search_lane keeps a node as fp, rp, sz, pos, meta, mm).
+// ------------------------------------------------------------------------------------------------
+
+// Of the non-empty children `alive` (bit nt = query symbol nt), those that make_child accepts.
+GM_HD uint32_t valid_children(uint32_t meta, int pos, int qc, uint32_t alive)
+{
+   const uint32_t match = qc == UNKNOWN ? 0x1fu : (1u << qc);
+   if ((meta >> META_DASH) & 1) return alive & match;
+   const int score = (meta >> META_SCORE) & 7, sref = (meta >> META_SREF) & 7, tau = (meta >> META_TAU) & 7,
+             diff = (meta >> META_DIFF) & 7, end = (meta >> META_END) & 255;
+   const bool last = pos == end;
+   const int s0 = score, s1 = score + 1;
+   const bool ok0 = s0 <= tau && (s0 == tau ? s0 - sref >= diff : !(last && s0 - sref < diff));
+   const bool ok1 = s1 <= tau && (s1 == tau ? s1 - sref >= diff : !(last && s1 - sref < diff));
+   return alive & ((ok0 ? match : 0u) | (ok1 ? ~match & 0x1fu : 0u));
+}
+
+// Child of a node through an accepted symbol nt: new meta (score, dash) and mismatch list; returns
+// true when the child has consumed the last position of its phase (CHILD_DONE).
+GM_HD bool child_meta(uint32_t meta, int pos, int qc, int nt, uint64_t mm, uint32_t &meta_out, uint64_t &mm_out)
+{
+   const uint32_t match = qc == UNKNOWN ? 0x1fu : (1u << qc);
+   const bool dash = (meta >> META_DASH) & 1;
+   const int score = (meta >> META_SCORE) & 7, tau = (meta >> META_TAU) & 7, end = (meta >> META_END) & 255;
+   const bool ds = !dash && !((match >> nt) & 1);
+   const int s = score + (ds ? 1 : 0);
+   mm_out = ds ? (mm | ((uint64_t)pos << (8 * score))) : mm;
+   meta_out = (meta & ~((7u << META_SCORE) | (1u << META_DASH) | (7u << META_FIRST))) | ((uint32_t)s << META_SCORE) |
+              ((uint32_t)(dash || s == tau) << META_DASH);
+   return pos == end;
+}
+
+// Phase records for k_search_lane: what a node becomes when it completes phase p.  Two words:
+//   x: meta template of the next phase (phase, dash = tau == 0, fw, end, tau, diff; score fields 0)
+//   y: start position of the next phase | final << 8 (final: the node is a hit of the read)
+GM_HD void phase_record(const uint32_t *table /* row of build_phase_table */, int p, uint32_t &x, uint32_t &y)
+{
+   int nxt = phase_next(table[p]);
+   if (nxt == PHASE_FINAL) { x = 0; y = 1u << 8; return; }
+   uint32_t e = table[nxt];
+   int start = e & 255, end = (e >> 8) & 255, fw = (e >> 16) & 1, tau = (e >> 17) & 15, diff = (e >> 21) & 15;
+   x = (uint32_t)nxt | ((uint32_t)(tau == 0) << META_DASH) | ((uint32_t)fw << META_FW) | ((uint32_t)end << META_END) |
+       ((uint32_t)tau << META_TAU) | ((uint32_t)diff << META_DIFF);
+   y = (uint32_t)start;
 }
 
 // Mismatch bitmap of a finished hit: the recorded mismatch positions plus every query N

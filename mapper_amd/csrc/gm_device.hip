@@ -73,7 +73,7 @@ struct gpumap_batch {
    int64_t n_reads = 0;
    int stride = 0;
    std::vector<int64_t> offsets;     // host copy (n_reads + 1)
-   DevBuf reads, read_len, len_row, phases, status;
+   DevBuf reads, read_len, len_row, phases, phase_rec, status;
    DevBuf hits, hit_sizes, hit_off, keys, keys_alt, read_cnt, read_first;
    DevBuf loc_read, loc_pos, loc_fwd, loc_seq, loc_seqpos, loc_strand, loc_score;
    DevBuf hkeys, hkeys_alt, hidx, hidx_alt, hit_read, hit_fp, hit_rp, hit_sz, hit_dp, hit_score, hit_align;
@@ -86,7 +86,7 @@ struct gpumap_batch {
    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
    void release()
    {
-      for (DevBuf *b : {&reads, &read_len, &len_row, &phases, &status, &hits, &hit_sizes, &hit_off, &keys, &keys_alt,
+      for (DevBuf *b : {&reads, &read_len, &len_row, &phases, &phase_rec, &status, &hits, &hit_sizes, &hit_off, &keys, &keys_alt,
                         &read_cnt, &read_first, &loc_read, &loc_pos, &loc_fwd, &loc_seq, &loc_seqpos, &loc_strand,
                         &loc_score, &hkeys, &hkeys_alt, &hidx, &hidx_alt, &hit_read, &hit_fp, &hit_rp, &hit_sz,
                         &hit_dp, &hit_score, &hit_align})
@@ -490,7 +490,7 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
       b->tau = tau; b->ran = false; b->n_hits = b->n_locs = b->n_ext = 0; b->have_intervals = false;
       // ---- schedule: one phase-table row per read length present (src/blocksearch.c:138-170)
       std::vector<uint8_t> len_row(MAX_READ + 1, 0xff);
-      std::vector<uint32_t> phases;
+      std::vector<uint32_t> phases, phase_rec;
       int rows = 0;
       for (int m = 1; m <= MAX_READ; m++) {
          if (!b->length_seen[m]) continue;
@@ -500,10 +500,17 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
          GM_FAIL_IF(rows >= 255, "too many distinct read lengths.");
          len_row[m] = (uint8_t)rows++;
          phases.insert(phases.end(), tab, tab + MAX_PHASES);
+         for (int p = 0; p < MAX_PHASES; p++) {
+            uint32_t x = 0, y = 0;
+            if (p < 3 * tau + 1) phase_record(tab, p, x, y);
+            phase_rec.push_back(x); phase_rec.push_back(y);
+         }
       }
-      if (phases.empty()) phases.assign(MAX_PHASES, 0);
+      if (phases.empty()) { phases.assign(MAX_PHASES, 0); phase_rec.assign(2 * MAX_PHASES, 0); }
       HIP_TRY(b->len_row.ensure(MAX_READ + 1));
       HIP_TRY(b->phases.ensure(4 * phases.size()));
+      HIP_TRY(b->phase_rec.ensure(4 * phase_rec.size()));
+      HIP_TRY(hipMemcpyAsync(b->phase_rec.p, phase_rec.data(), 4 * phase_rec.size(), hipMemcpyHostToDevice, st));
       HIP_TRY(hipMemcpyAsync(b->len_row.p, len_row.data(), MAX_READ + 1, hipMemcpyHostToDevice, st));
       HIP_TRY(hipMemcpyAsync(b->phases.p, phases.data(), 4 * phases.size(), hipMemcpyHostToDevice, st));
       if (R > 0) {
@@ -530,6 +537,7 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
          A.ix = ctx->ix;
          A.reads = b->reads.as<const uint8_t>(); A.read_len = b->read_len.as<const uint16_t>();
          A.len_row = b->len_row.as<const uint8_t>(); A.phases = b->phases.as<const uint32_t>();
+         A.phase_rec = b->phase_rec.as<const uint2>(); A.n_rows = std::max(rows, 1);
          A.n_reads = R; A.stride = b->stride; A.tau = tau;
          A.cursor = cnt + 0; A.hits = b->hits.as<Node>(); A.hit_cap = hit_cap; A.hit_count = cnt + 1; A.n_ext = cnt + 2;
          A.spill = ctx->spill.as<Node>(); A.spill_cap = (uint32_t)ctx->spill_cap; A.error = (int *)(cnt + 3); A.stats = cnt + 4;

@@ -209,6 +209,8 @@ struct SearchArgs {
    const uint16_t *read_len;    // [n_reads]
    const uint8_t  *len_row;     // [MAX_READ + 1] -> row of `phases`, 0xff = the reference returns -1
    const uint32_t *phases;      // [rows][MAX_PHASES]
+   const uint2    *phase_rec;   // [rows][MAX_PHASES] what a node becomes at the end of a phase (phase_record)
+   int n_rows;
    int64_t n_reads;
    int stride, tau;
    unsigned long long *cursor;  // next read to admit
@@ -219,7 +221,7 @@ struct SearchArgs {
    Node *spill;                 // [waves][spill_cap]
    uint32_t spill_cap;
    int *error;                  // set to 1 when a spill region overflows
-   unsigned long long *stats;   // [0] passes of the main loop over all waves, [1] passes of the child loop
+   unsigned long long *stats;   // [0] passes of the main loop over all waves, [1] continuations pushed
 };
 
 __device__ __forceinline__ uint32_t quad_sum(uint32_t x)

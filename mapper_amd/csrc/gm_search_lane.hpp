@@ -58,49 +58,66 @@ __device__ __forceinline__ void hit_emit(const SearchArgs &A, HitRing &hr, bool 
    if (hr.tail - hr.head >= 64) hit_flush(A, hr, lane, 64);
 }
 
-// Broadcast of lane i's value to its quad (DPP quad_perm [i,i,i,i]); every lane must be active.
+// Lanes whose quad's lane I is set in `m`: the execution mask of fetch slot I (scalar work only).
 template <int I>
-__device__ __forceinline__ uint32_t quad_bcast(uint32_t x)
+__device__ __forceinline__ unsigned long long quad_spread(unsigned long long m)
 {
-   return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, I * 0x55, 0xF, 0xF, true);
+   unsigned long long t = (m >> I) & 0x1111111111111111ull;
+   t |= t << 1;
+   return t | (t << 2);
+}
+
+// Fetch slot I: the quad reads the block of its lane I, 16 bytes per lane.  `off` is the byte offset
+// of the lane's own block; Occ tables are below 4 GiB (n < 2^33), so a 32-bit offset from the
+// scalar base addresses them.
+template <int I>
+__device__ __forceinline__ void quad_fetch(const char *occ, uint32_t off, unsigned long long want, uint32_t sub16, uint4 &v)
+{
+   uint32_t o = (uint32_t)__builtin_amdgcn_mov_dpp((int)off, I * 0x55, 0xF, 0xF, true) + sub16;
+   if (__builtin_amdgcn_inverse_ballot_w64(quad_spread<I>(want)))
+      v = *reinterpret_cast<const uint4 *>(occ + o);
 }
 
 template <int I>
-__device__ __forceinline__ void quad_fetch(const uint4 *occ4, uint32_t blk, bool want, int sub, uint4 &v)
+__device__ __forceinline__ void quad_stage(uint4 *slot /* stage + quad*4*SLOT + sub */, unsigned long long want, const uint4 &v)
 {
-   uint32_t b = quad_bcast<I>(blk);
-   bool w = quad_bcast<I>((uint32_t)want) != 0;
-   if (w) v = occ4[(size_t)b * 4 + sub];
+   if (__builtin_amdgcn_inverse_ballot_w64(quad_spread<I>(want))) slot[I * STAGE_SLOT_U4] = v;
 }
 
-template <int I>
-__device__ __forceinline__ void quad_stage(uint4 *stage, bool want, int lane, int sub, const uint4 &v)
+// Rank inside one block held by one lane: counts (relative to the superblock) of the five symbols in
+// BWT[superblock start, block start + o), o = 0..127.  Same result as block_rank (gm_core.hpp).
+__device__ __forceinline__ void lane_rank(const uint4 &s0, const uint4 &s1, const uint4 &s2, const uint4 &s3, int o,
+                                          uint32_t rel[SYMS])
 {
-   bool w = quad_bcast<I>((uint32_t)want) != 0;
-   if (w) stage[((lane & ~3) + I) * STAGE_SLOT_U4 + sub] = v;
+   const unsigned long long t = (1ull << (o & 63)) - 1ull;
+   const unsigned long long lo = o >= 64 ? ~0ull : t, hi = o >= 64 ? t : 0ull;
+   const uint32_t m0 = (uint32_t)lo, m1 = (uint32_t)(lo >> 32), m2 = (uint32_t)hi, m3 = (uint32_t)(hi >> 32);
+   uint32_t a = s0.w & CNT_MASK, c = s1.w & CNT_MASK, g = s2.w & CNT_MASK, tt = s3.w & CNT_MASK;
+   uint32_t n = (s0.w >> 25) | ((s1.w >> 25) << 7) | ((s2.w >> 25) << 14) | ((s3.w >> 25) << 21);
+#define GM_SUB(S, M) { \
+      const uint32_t x = ~S.z & M; \
+      a += __popc(x & ~S.y & ~S.x); c += __popc(x & ~S.y & S.x); g += __popc(x & S.y & ~S.x); tt += __popc(x & S.y & S.x); \
+      n += __popc(S.z & ~S.x & M); }
+   GM_SUB(s0, m0) GM_SUB(s1, m1) GM_SUB(s2, m2) GM_SUB(s3, m3)
+#undef GM_SUB
+   rel[0] = a; rel[1] = c; rel[2] = g; rel[3] = tt; rel[4] = n;
 }
 
-__device__ __forceinline__ void stage_read(const uint4 *stage, int lane, uint32_t blk[BLOCK_DWORDS])
-{
-   const uint4 *s = stage + lane * STAGE_SLOT_U4;
-#pragma unroll
-   for (int k = 0; k < 4; k++) {
-      uint4 t = s[k];
-      blk[4 * k] = t.x; blk[4 * k + 1] = t.y; blk[4 * k + 2] = t.z; blk[4 * k + 3] = t.w;
-   }
-}
+constexpr int PH_LDS_ROWS = 16;      // phase-record rows (read lengths) kept in LDS; others are read from global memory
 
 __global__ void __launch_bounds__(WG_THREADS) k_search_lane(SearchArgs A)
 {
    __shared__ Node s_q[WG_WAVES][LQCAP];
    __shared__ uint4 s_stage[WG_WAVES][64 * STAGE_SLOT_U4];
    __shared__ Node s_hit[WG_WAVES][HITBUF];
+   __shared__ uint2 s_ph[PH_LDS_ROWS * MAX_PHASES];
    extern __shared__ unsigned long long s_cb[];              // C[j] + count of j before superblock s
 
    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, sub = lane & 3;
    const uint32_t gw = blockIdx.x * WG_WAVES + wid;
    for (int i = tid; i < (int)A.ix.n_super * SYMS; i += WG_THREADS)
       s_cb[i] = A.ix.tables[TAB_SBASE + i] + A.ix.tables[TAB_C + i % SYMS];
+   for (int i = tid; i < min(A.n_rows, PH_LDS_ROWS) * MAX_PHASES; i += WG_THREADS) s_ph[i] = A.phase_rec[i];
    __syncthreads();
 
    WaveQueue wq;
@@ -110,31 +127,35 @@ __global__ void __launch_bounds__(WG_THREADS) k_search_lane(SearchArgs A)
    wq.spill_cap = A.spill_cap;
    wq.error = A.error;
    uint4 *stage = s_stage[wid];
+   uint4 *stage_w = stage + (lane & ~3) * STAGE_SLOT_U4 + sub;      // where this lane writes slot 0 of its quad
+   const uint4 *stage_r = stage + lane * STAGE_SLOT_U4;             // this lane's own block
    HitRing hr;
    hr.ring = s_hit[wid];
    hr.head = hr.tail = 0;
-   unsigned long long n_iter = 0, n_child_iter = 0;
+   unsigned long long n_iter = 0, n_cont = 0;
 
    const int seeds_per = A.tau + 1;
    const int reads_per_refill = 64 / seeds_per;
    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-   const uint4 *occ4 = reinterpret_cast<const uint4 *>(A.ix.occ);
+   const char *occ = reinterpret_cast<const char *>(A.ix.occ);
+   const uint32_t sub16 = (uint32_t)sub << 4;
 
    bool reads_left = true;
    bool have = false;
-   NodeR cur;
-   cur.fp = cur.rp = cur.sz = 0; cur.read = 0; cur.mm = 0;
-   cur.pos = cur.end = cur.phase = cur.score = cur.sref = cur.tau = cur.diff = 0;
-   cur.dash = cur.fw = false;
-   uint32_t qword = 0;          // four query symbols around cur.pos
-   int qword_at = -1;           // cur.pos >> 2 of the cached word, -1 = none
+   // the node of this lane
+   int64_t fp = 0, rp = 0, sz = 0;
+   uint64_t mm = 0;
+   uint32_t read = 0, meta = 0;
+   int pos = 0;
+   uint32_t qword = 0;          // four query symbols around pos
+   int qword_at = -1;           // pos >> 2 of the cached word, -1 = none
    unsigned long long ext_count = 0;
 
    for (;;) {
       // ------------------------------------------------------------ hand nodes to idle lanes
       unsigned long long needm = __ballot(!have);
-      int nneed = __popcll(needm);
-      if (nneed) {
+      if (needm) {
+         int nneed = __popcll(needm);
          int count = (int)(wq.top - wq.bot);
          if (count < nneed) {
             if (wq.spill_top > 0) {
@@ -162,14 +183,14 @@ __global__ void __launch_bounds__(WG_THREADS) k_search_lane(SearchArgs A)
                   Node packed;
                   for (int k = 0; k < 8; k++) packed.w[k] = 0;
                   if (mk) {
-                     uint32_t read = (uint32_t)(base + r);
-                     int m = A.read_len[read];
+                     uint32_t rd = (uint32_t)(base + r);
+                     int m = A.read_len[rd];
                      int row = m <= MAX_READ ? A.len_row[m] : 0xff;
                      mk = row != 0xff;
                      if (mk) {
                         NodeR sd;
                         sd.fp = 0; sd.rp = 0; sd.sz = A.ix.n;        // bwt_new_query, src/index_bwt.c:48-52
-                        sd.read = read; sd.score = 0; sd.mm = (uint64_t)row << 56;
+                        sd.read = rd; sd.score = 0; sd.mm = (uint64_t)row << 56;
                         sd.sref = 0; sd.pos = sd.end = sd.tau = sd.diff = sd.phase = 0; sd.dash = sd.fw = false;
                         enter_phase(sd, leaf, A.phases[row * MAX_PHASES + leaf]);
                         pack_node(sd, packed);
@@ -186,7 +207,12 @@ __global__ void __launch_bounds__(WG_THREADS) k_search_lane(SearchArgs A)
             if (rank < count) {
                Node nd;
                lds_load_node<LQCAP>(wq.q, wq.top - 1 - (uint32_t)rank, nd);
-               unpack_node(nd, cur);
+               fp = (int64_t)nd.w[0] | ((int64_t)(nd.w[3] & 0xff) << 32);
+               rp = (int64_t)nd.w[1] | ((int64_t)((nd.w[3] >> 8) & 0xff) << 32);
+               sz = (int64_t)nd.w[2] | ((int64_t)((nd.w[3] >> 16) & 0xff) << 32);
+               pos = (int)(nd.w[3] >> 24);
+               read = nd.w[4]; meta = nd.w[5];
+               mm = (uint64_t)nd.w[6] | ((uint64_t)nd.w[7] << 32);
                have = true;
                qword_at = -1;
             }
@@ -194,108 +220,127 @@ __global__ void __launch_bounds__(WG_THREADS) k_search_lane(SearchArgs A)
          wq.top -= (uint32_t)min(nneed, count);
          wave_sync();
       }
-      if (!__any(have)) {
+      const unsigned long long havem = __ballot(have);
+      if (!havem) {
          if (!reads_left && wq.spill_top == 0 && wq.top == wq.bot) break;
          continue;
       }
-      ext_count += (unsigned long long)__popcll(__ballot(have));
+      const int first = (int)(meta >> META_FIRST) & 7;
+      ext_count += (unsigned long long)__popcll(__ballot(have && first == 0));   // a continuation was counted at its first visit
       n_iter++;
 
       // ------------------------------------------------------------ fetch: all loads first, then the hand-over
-      const int64_t a = cur.fw ? cur.rp : cur.fp, other = cur.fw ? cur.fp : cur.rp;
-      const int64_t e0 = a, e1 = a + cur.sz;                       // ranks at a-1 and a+sz-1, exclusive form
+      const bool fw = (meta >> META_FW) & 1;
+      const int64_t a = fw ? rp : fp, other = fw ? fp : rp;
+      const int64_t e0 = a, e1 = a + sz;                           // ranks at a-1 and a+sz-1, exclusive form
       const uint32_t b0 = (uint32_t)(e0 >> BLOCK_POS_LOG), b1 = (uint32_t)(e1 >> BLOCK_POS_LOG);
-      const bool need1 = have && b1 != b0;
+      const unsigned long long need1m = __ballot(have && b1 != b0);
       uint4 f00, f01, f02, f03, f10, f11, f12, f13;
       f00 = f01 = f02 = f03 = f10 = f11 = f12 = f13 = make_uint4(0, 0, 0, 0);
-      quad_fetch<0>(occ4, b0, have, sub, f00); quad_fetch<1>(occ4, b0, have, sub, f01);
-      quad_fetch<2>(occ4, b0, have, sub, f02); quad_fetch<3>(occ4, b0, have, sub, f03);
-      quad_fetch<0>(occ4, b1, need1, sub, f10); quad_fetch<1>(occ4, b1, need1, sub, f11);
-      quad_fetch<2>(occ4, b1, need1, sub, f12); quad_fetch<3>(occ4, b1, need1, sub, f13);
-      if (have && (cur.pos >> 2) != qword_at) {
-         qword_at = cur.pos >> 2;
-         qword = *reinterpret_cast<const uint32_t *>(A.reads + (size_t)cur.read * A.stride + (cur.pos & ~3));
+      quad_fetch<0>(occ, b0 << 6, havem, sub16, f00); quad_fetch<1>(occ, b0 << 6, havem, sub16, f01);
+      quad_fetch<2>(occ, b0 << 6, havem, sub16, f02); quad_fetch<3>(occ, b0 << 6, havem, sub16, f03);
+      if (need1m) {
+         quad_fetch<0>(occ, b1 << 6, need1m, sub16, f10); quad_fetch<1>(occ, b1 << 6, need1m, sub16, f11);
+         quad_fetch<2>(occ, b1 << 6, need1m, sub16, f12); quad_fetch<3>(occ, b1 << 6, need1m, sub16, f13);
       }
-      const int qc = (int)((qword >> (8 * (cur.pos & 3))) & 0xff);
+      if (have && (pos >> 2) != qword_at) {
+         qword_at = pos >> 2;
+         qword = *reinterpret_cast<const uint32_t *>(A.reads + (size_t)read * A.stride + (pos & ~3));
+      }
 
-      uint32_t blk[BLOCK_DWORDS];
       uint32_t rel0[SYMS], rel1[SYMS];
-      quad_stage<0>(stage, have, lane, sub, f00); quad_stage<1>(stage, have, lane, sub, f01);
-      quad_stage<2>(stage, have, lane, sub, f02); quad_stage<3>(stage, have, lane, sub, f03);
+      uint4 g0 = make_uint4(0, 0, 0, 0), g1 = g0, g2 = g0, g3 = g0;
+      quad_stage<0>(stage_w, havem, f00); quad_stage<1>(stage_w, havem, f01);
+      quad_stage<2>(stage_w, havem, f02); quad_stage<3>(stage_w, havem, f03);
       wave_sync();
-      for (int k = 0; k < BLOCK_DWORDS; k++) blk[k] = 0;
-      if (have) stage_read(stage, lane, blk);
-      block_rank(blk, (int)(e0 & (BLOCK_POS - 1)), rel0);
+      if (have) { g0 = stage_r[0]; g1 = stage_r[1]; g2 = stage_r[2]; g3 = stage_r[3]; }
+      lane_rank(g0, g1, g2, g3, (int)(e0 & (BLOCK_POS - 1)), rel0);
+      if (need1m) {
+         wave_sync();
+         quad_stage<0>(stage_w, need1m, f10); quad_stage<1>(stage_w, need1m, f11);
+         quad_stage<2>(stage_w, need1m, f12); quad_stage<3>(stage_w, need1m, f13);
+         wave_sync();
+         if (have && b1 != b0) { g0 = stage_r[0]; g1 = stage_r[1]; g2 = stage_r[2]; g3 = stage_r[3]; }
+      }
+      lane_rank(g0, g1, g2, g3, (int)(e1 & (BLOCK_POS - 1)), rel1);
       wave_sync();
-      quad_stage<0>(stage, need1, lane, sub, f10); quad_stage<1>(stage, need1, lane, sub, f11);
-      quad_stage<2>(stage, need1, lane, sub, f12); quad_stage<3>(stage, need1, lane, sub, f13);
-      wave_sync();
-      if (need1) stage_read(stage, lane, blk);
-      block_rank(blk, (int)(e1 & (BLOCK_POS - 1)), rel1);
-      wave_sync();
+      const int qc = (int)((qword >> (8 * (pos & 3))) & 0xff);
 
       // ------------------------------------------------------------ bwt_query_all, src/index_bwt.c:262-273
       const int sb0 = (int)(e0 >> SUPER_LOG), sb1 = (int)(e1 >> SUPER_LOG);
-      int64_t szn[SYMS], rpn[SYMS];
+      int64_t szn[SYMS];
       for (int j = 0; j < SYMS; j++) szn[j] = (int64_t)rel1[j] - (int64_t)rel0[j];
       if (have && sb1 != sb0)
          for (int j = 0; j < SYMS; j++) szn[j] += (int64_t)(s_cb[sb1 * SYMS + j] - s_cb[sb0 * SYMS + j]);
       const int64_t tot = szn[0] + szn[1] + szn[2] + szn[3] + szn[4];
-      rpn[3] = other + (cur.sz - tot);
-      rpn[2] = rpn[3] + szn[3];
-      rpn[1] = rpn[2] + szn[2];
-      rpn[0] = rpn[1] + szn[1];
-      rpn[4] = rpn[0] + szn[0];
 
-      // candidate query symbols: non-empty children; the dash follows only the query symbol (N: all)
-      uint32_t cand = 0;
-      if (have) {
-         uint32_t alive = (szn[0] >= 1 ? 1u : 0u) | (szn[1] >= 1 ? 2u : 0u) | (szn[2] >= 1 ? 4u : 0u) |
-                          (szn[3] >= 1 ? 8u : 0u) | (szn[4] >= 1 ? 16u : 0u);           // by internal symbol
-         if (cur.fw) alive = ((alive & 1u) << 3) | ((alive & 2u) << 1) | ((alive & 4u) >> 1) | ((alive & 8u) >> 3) | (alive & 16u);
-         cand = alive;                                                                   // by query symbol
-         if (cur.dash && qc != UNKNOWN) cand &= 1u << qc;
-      }
-      const int row = (int)(cur.mm >> 56);
-      NodeR next = cur;
-      bool kept = false;
-      while (__any(cand != 0)) {
-         n_child_iter++;
-         bool push = false, emit = false;
+      // non-empty children by internal symbol, then by query symbol (forward: complemented)
+      uint32_t alive = (szn[0] >= 1 ? 1u : 0u) | (szn[1] >= 1 ? 2u : 0u) | (szn[2] >= 1 ? 4u : 0u) |
+                       (szn[3] >= 1 ? 8u : 0u) | (szn[4] >= 1 ? 16u : 0u);
+      if (fw) alive = (__brev(alive & 15u) >> 28) | (alive & 16u);
+      uint32_t cand = have ? valid_children(meta, pos, qc, alive) & (0x1fu << first) : 0u;
+
+      // ------------------------------------------------------------ this pass follows the first candidate;
+      // the others stay behind as a continuation of the same node (re-extended when it is popped)
+      const bool cont = (cand & (cand - 1)) != 0;
+      if (__any(cont)) {
          Node out;
-         for (int k = 0; k < 8; k++) out.w[k] = 0;
-         if (cand != 0) {
-            const int nt = __ffs((int)cand) - 1;
-            cand &= cand - 1;
-            const int js = cur.fw ? complement(nt) : nt;
-            const int64_t fpn = (int64_t)(s_cb[sb0 * SYMS + js] + sel5(rel0, js));
-            const int64_t rp_ = sel5(rpn, js), sz_ = sel5(szn, js);
-            NodeR child;
-            int kind = make_child(cur, nt, qc, cur.fw ? rp_ : fpn, cur.fw ? fpn : rp_, sz_, child);
-            if (kind == CHILD_DONE) {
-               int nxt = phase_next(A.phases[row * MAX_PHASES + cur.phase]);
-               if (nxt == PHASE_FINAL) { emit = true; child.pos = 0; pack_node(child, out); kind = CHILD_NONE; }
-               else { enter_phase(child, nxt, A.phases[row * MAX_PHASES + nxt]); kind = CHILD_NODE; }
-            }
-            if (kind == CHILD_NODE) {
-               if (!kept) { next = child; kept = true; }
-               else { push = true; pack_node(child, out); }
+         out.w[0] = (uint32_t)fp; out.w[1] = (uint32_t)rp; out.w[2] = (uint32_t)sz;
+         out.w[3] = (uint32_t)((fp >> 32) & 0xff) | ((uint32_t)((rp >> 32) & 0xff) << 8) |
+                    ((uint32_t)((sz >> 32) & 0xff) << 16) | ((uint32_t)pos << 24);
+         out.w[4] = read;
+         const uint32_t rest = cand & (cand - 1);
+         out.w[5] = (meta & ~(7u << META_FIRST)) | ((uint32_t)(__ffs((int)rest) - 1) << META_FIRST);
+         out.w[6] = (uint32_t)mm; out.w[7] = (uint32_t)(mm >> 32);
+         wave_push<LQCAP, LCHUNK>(wq, cont, out, lane);
+         n_cont += (unsigned long long)__popcll(__ballot(cont));
+      }
+      bool emit = false;
+      if (cand != 0) {
+         const int nt = __ffs((int)cand) - 1;
+         const int js = fw ? complement(nt) : nt;
+         // the pointer on the side that was not extended accumulates in the order T,G,C,A,N (:270-273)
+         const int64_t r3 = other + (sz - tot), r2 = r3 + szn[3], r1 = r2 + szn[2], r0 = r1 + szn[1], r4 = r0 + szn[0];
+         const int64_t fpn = (int64_t)(s_cb[sb0 * SYMS + js] + sel5(rel0, js));
+         const int64_t rpn = sel5v(r0, r1, r2, r3, r4, js);
+         sz = sel5(szn, js);
+         fp = fw ? rpn : fpn;
+         rp = fw ? fpn : rpn;
+         uint32_t meta_n;
+         const bool done = child_meta(meta, pos, qc, nt, mm, meta_n, mm);
+         meta = meta_n;
+         pos = fw ? pos + 1 : pos - 1;
+         if (done) {
+            const int idx = (int)(mm >> 56) * MAX_PHASES + (int)(meta & 63);
+            const uint2 rec = idx < PH_LDS_ROWS * MAX_PHASES ? s_ph[idx] : A.phase_rec[idx];
+            if (rec.y >> 8) {
+               emit = true;
+               pos = 0;
+            } else {
+               const uint32_t s = (meta >> META_SCORE) & 7;
+               meta = rec.x | (s << META_SCORE) | (s << META_SREF);
+               pos = (int)rec.y;
             }
          }
-         if (__any(push)) wave_push<LQCAP, LCHUNK>(wq, push, out, lane);
+      } else {
+         have = false;
+      }
+      if (__any(emit)) {
+         Node out;
+         out.w[0] = (uint32_t)fp; out.w[1] = (uint32_t)rp; out.w[2] = (uint32_t)sz;
+         out.w[3] = (uint32_t)((fp >> 32) & 0xff) | ((uint32_t)((rp >> 32) & 0xff) << 8) |
+                    ((uint32_t)((sz >> 32) & 0xff) << 16);
+         out.w[4] = read; out.w[5] = meta;
+         out.w[6] = (uint32_t)mm; out.w[7] = (uint32_t)(mm >> 32);
          hit_emit(A, hr, emit, out, lane);
+         if (emit) have = false;
       }
-      if (have) {
-         cur = next;
-         have = kept;
-      }
-      wave_sync();
    }
    if (hr.tail != hr.head) hit_flush(A, hr, lane, hr.tail - hr.head);
    if (lane == 0 && ext_count) {
       atomicAdd(A.n_ext, ext_count);
       atomicAdd(A.stats + 0, n_iter);
-      atomicAdd(A.stats + 1, n_child_iter);
+      atomicAdd(A.stats + 1, n_cont);
    }
 }
 

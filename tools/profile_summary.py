@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Condenses the rocprofv3 output of tools/profile_passes.sh into one JSON document:
+kernel-trace stats of our kernels and, per PMC counter, the average per launch of the search kernel."""
+import csv, glob, json, os, sys
+
+def main(root):
+    out = {"kernel_stats": [], "pmc_per_launch": {}, "bench_lines": {}}
+    for f in glob.glob(os.path.join(root, "stats", "**", "*kernel_stats.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            name = r["Name"]
+            if "gm::" in name:
+                out["kernel_stats"].append({"kernel": name.split("(")[0], "calls": int(r["Calls"]),
+                                            "avg_ns": float(r["AverageNs"]), "pct": float(r["Percentage"])})
+    for f in sorted(glob.glob(os.path.join(root, "pmc*", "**", "*counter_collection.csv"), recursive=True)):
+        acc = {}
+        for r in csv.DictReader(open(f)):
+            if "k_search" not in r["Kernel_Name"]:
+                continue
+            key = (r["Kernel_Name"].split("(")[0], r["Counter_Name"])
+            d = acc.setdefault(key, {})
+            d[r["Dispatch_Id"]] = d.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
+        for (k, c), d in acc.items():
+            vals = list(d.values())
+            out["pmc_per_launch"].setdefault(k, {})[c] = {"launches": len(vals), "avg": sum(vals) / len(vals)}
+    for f in sorted(glob.glob(os.path.join(root, "*.json"))):
+        if os.path.basename(f) == "summary.json":
+            continue
+        try:
+            d = json.loads(open(f).read().strip().splitlines()[-1])
+            out["bench_lines"][os.path.basename(f)] = {"value": d["value"], "kernel_ms": d["roofline"]["kernel_ms"],
+                                                       "ext_steps": d["roofline"]["ext_steps_per_launch"]}
+        except Exception as e:  # a pass without a bench line
+            out["bench_lines"][os.path.basename(f)] = str(e)
+    print(json.dumps(out, indent=1))
+
+if __name__ == "__main__":
+    main(sys.argv[1])
