@@ -521,7 +521,7 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
       HIP_TRY(hipStreamSynchronize(st));          // the staging vectors above go out of scope
 
       // ---- K2 search (rerun once with an exact buffer if the hit list overflowed)
-      const int wpc = ctx->waves_per_cu ? ctx->waves_per_cu : (ctx->variant == 1 ? 8 : 12);
+      const int wpc = ctx->waves_per_cu ? ctx->waves_per_cu : 12;
       const int n_wg = std::max(1, ctx->cu_count * wpc / WG_WAVES);
       const int64_t n_waves = (int64_t)n_wg * WG_WAVES;
       HIP_TRY(ctx->spill.ensure((size_t)n_waves * (size_t)ctx->spill_cap * sizeof(Node)));

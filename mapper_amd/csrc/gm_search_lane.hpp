@@ -21,10 +21,10 @@ namespace gm {
 constexpr int LQCAP = 128;           // deque capacity per wave (nodes), power of two
 constexpr int LCHUNK = 64;           // nodes moved per spill / reload
 constexpr int STAGE_SLOT_U4 = 5;     // staging slot per lane, in 16-byte units (4 used + 1 pad)
-constexpr int HITBUF = 128;          // finished nodes staged per wave before they go to the global list
+constexpr int HITBUF = 64;           // finished nodes staged per wave before they go to the global list
 
-// Finished nodes are staged in a per-wave LDS ring and leave it 64 at a time: one atomic on the
-// global counter and one contiguous 2-KB store per 64 hits.  (One atomic per emitting pass, as in
+// Finished nodes are staged in a per-wave LDS ring and leave it when the next ones would not fit: one
+// atomic on the global counter and one contiguous store of up to 2 KB per flush.  (One atomic per emitting pass, as in
 // k_search, serialises all waves on one address: about 10 ns per atomic, the whole kernel time.)
 struct HitRing {
    Node *ring;
@@ -52,10 +52,11 @@ __device__ __forceinline__ void hit_emit(const SearchArgs &A, HitRing &hr, bool 
 {
    unsigned long long m = __ballot(flag);
    if (m == 0) return;
+   const uint32_t add = (uint32_t)__popcll(m);
+   if (hr.tail - hr.head + add > HITBUF) hit_flush(A, hr, lane, hr.tail - hr.head);
    if (flag) lds_store_node<HITBUF>(hr.ring, hr.tail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), nd);
-   hr.tail += (uint32_t)__popcll(m);
+   hr.tail += add;
    wave_sync();
-   if (hr.tail - hr.head >= 64) hit_flush(A, hr, lane, 64);
 }
 
 // Lanes whose quad's lane I is set in `m`: the execution mask of fetch slot I (scalar work only).
@@ -103,7 +104,7 @@ __device__ __forceinline__ void lane_rank(const uint4 &s0, const uint4 &s1, cons
    rel[0] = a; rel[1] = c; rel[2] = g; rel[3] = tt; rel[4] = n;
 }
 
-constexpr int PH_LDS_ROWS = 16;      // phase-record rows (read lengths) kept in LDS; others are read from global memory
+constexpr int PH_LDS_ROWS = 8;       // phase-record rows (read lengths) kept in LDS; others are read from global memory
 
 __global__ void __launch_bounds__(WG_THREADS) k_search_lane(SearchArgs A)
 {
