@@ -96,6 +96,22 @@ gpumap_ctx *gpumap_create(const gpumap_index_view *view, int device);
 gpumap_ctx *gpumap_create_from_files(const char *filename_base, int device);
 void        gpumap_destroy(gpumap_ctx *ctx);
 
+/* index_build on the device: the reference builds on the host (src/index.c:99-162: txt_commit_rc,
+** sar_build = divsufsort + compact_array, bwt_build_opt), which takes hours at GRCh38 size; this
+** produces the same arrays in HBM (text F$rc(F)$, packed suffix array, Occ array in the reference's
+** layout; bit-identical to the host builder's) and the rank blocks from them.  `codes`: the
+** sequences' symbol codes (0..4) one after another, in host memory or (codes_on_device != 0) in
+** device memory; seq_lens[seq_cnt].  keep_reference != 0 keeps the text and the reference-layout Occ
+** array in HBM so that gpumap_reference_fetch can hand them out (e.g. to write base.* files). */
+gpumap_ctx *gpumap_build_device(const uint8_t *codes, int codes_on_device, const int64_t *seq_lens,
+                                int64_t seq_cnt, int device, int keep_reference);
+/* sizes[0] = txt_len, [1] = occ_length (64-bit words), [2] = sar_len (words), [3] = sar_bits,
+** [4] = wil_cnt, [5] = bytes of text kept (0 if none). */
+int         gpumap_reference_sizes(const gpumap_ctx *ctx, int64_t sizes[6]);
+/* Copies to host memory (any pointer may be NULL): the .bwt Occ array and c[6], the .sar array,
+** the .txt text. */
+int         gpumap_reference_fetch(gpumap_ctx *ctx, uint64_t *occ, uint64_t c[6], int64_t *sa, uint8_t *text);
+
 /* Device-resident index arrays, for replication across GPUs (rank 0 exports, RCCL broadcasts the
 ** three buffers, the other ranks import).  Pointers are device pointers; sizes in bytes.
 ** `header` is a small host blob (gpumap_devindex_header_size() bytes) describing the layout. */

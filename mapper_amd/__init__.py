@@ -85,6 +85,9 @@ API = {
     "gpumap_batch_free": (None, [_P]),
     "gpumap_mapper": (_I, [C.c_char_p, _P, _P, _I, C.c_char_p]),
     "gpumap_set_option": (_I, [_P, C.c_char_p, _I64]),
+    "gpumap_build_device": (_P, [_P, _I, _P, _I64, _I, _I]),
+    "gpumap_reference_sizes": (_I, [_P, C.POINTER(_I64)]),
+    "gpumap_reference_fetch": (_I, [_P, _P, _P, _P, _P]),
     "gpumap_version": (C.c_char_p, []),
 }
 # host-side extra (not in the reference): index from code arrays, for synthetic genomes
@@ -271,6 +274,30 @@ class Context:
     def from_device(cls, dev, header, device=0, keep=None):
         hb = np.frombuffer(bytes(header), dtype=np.uint8).copy()
         return cls(lib().gpumap_create_from_device(C.byref(dev), _ptr(hb), device), keep=keep)
+
+    @classmethod
+    def build_device(cls, seqs, device=0, keep_reference=False, device_ptr=None):
+        """index_build on the GPU.  seqs: list of uint8 code arrays, or (device_ptr != None) their
+        lengths only, the codes lying one after another in device memory at device_ptr."""
+        if device_ptr is None:
+            codes = np.ascontiguousarray(np.concatenate(seqs), dtype=np.uint8)
+            lens = np.array([len(x) for x in seqs], dtype=np.int64)
+            return cls(lib().gpumap_build_device(_ptr(codes), 0, _ptr(lens), len(lens), device, int(keep_reference)))
+        lens = np.ascontiguousarray(seqs, dtype=np.int64)
+        return cls(lib().gpumap_build_device(C.c_void_p(int(device_ptr)), 1, _ptr(lens), len(lens), device, int(keep_reference)))
+
+    def reference_arrays(self, want_text=True):
+        """Host copies of the arrays a device build kept: dict(txt_len, sar_bits, wil_cnt, occ, c, sa, text)."""
+        sz = (_I64 * 6)()
+        if lib().gpumap_reference_sizes(self._h, sz) != 0:
+            raise GpumapError("gpumap_reference_sizes failed")
+        occ = np.empty(sz[1], dtype=np.uint64)
+        c = np.zeros(6, dtype=np.uint64)
+        sa = np.empty(sz[2], dtype=np.int64)
+        text = np.empty(sz[5], dtype=np.uint8) if want_text and sz[5] else None
+        if lib().gpumap_reference_fetch(self._h, _ptr(occ), _ptr(c), _ptr(sa), _ptr(text) if text is not None else None) != 0:
+            raise GpumapError("gpumap_reference_fetch failed (see stderr)")
+        return dict(txt_len=sz[0], sar_bits=sz[3], wil_cnt=sz[4], occ=occ, c=c, sa=sa, text=text)
 
     def export(self):
         dev = DevIndex()

@@ -1,0 +1,88 @@
+// gm_devctx.hpp -- device context shared by the translation units that launch kernels
+// (gm_device.hip: query path; gm_build.hip: index construction on the device).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cerrno>
+#include <cstdio>
+#include "gm_host.hpp"
+#include "gm_core.hpp"
+
+namespace gm {
+struct IndexDev {
+   const uint32_t *occ;        // rank blocks, 16 dwords each
+   const uint64_t *tables;
+   const uint64_t *sa;         // packed suffix array, verbatim
+   const int64_t  *seq_beg;
+   int64_t n;                  // text length
+   int64_t n_blocks, n_super;
+   int32_t sar_bits;
+   int32_t seq_cnt;
+};
+constexpr int MAX_SB_LDS = 256;      // superblocks whose counts are staged in LDS (n < 2^33)
+constexpr int TAB_C = 0;             // `tables` (64-bit words): [0..4] C[0..4];
+constexpr int TAB_SBASE = 8;         // [8 + 5*s + j] absolute count of symbol j in BWT[0, s << 25)
+}  // namespace gm
+
+#define HIP_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+   std::fprintf(stderr, "%s\t(%s:%d) error: %s: %s\n", __func__, __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+   errno = 1; goto failure_return; } } while (0)
+
+struct DevBuf {
+   void *p = nullptr;
+   size_t cap = 0;
+   hipError_t ensure(size_t bytes)
+   {
+      if (bytes <= cap) return hipSuccess;
+      if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+      size_t want = bytes + bytes / 4 + 256;
+      hipError_t e = hipMalloc(&p, want);
+      if (e != hipSuccess) { e = hipMalloc(&p, bytes); want = bytes; }
+      if (e == hipSuccess) cap = want;
+      return e;
+   }
+   void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+   template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct DevIndexHeader {          // host blob that travels with an exported device index
+   uint64_t magic;
+   int64_t  n, n_blocks, n_super, sar_bits, sar_len, seq_cnt, tables_words;
+   uint8_t  sym_table[256];
+   uint8_t  com_table[8];
+};
+constexpr uint64_t DEVINDEX_MAGIC = 0x47504d4158444e49ULL;
+
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+struct gpumap_ctx {
+   int device = 0;
+   hipStream_t stream = nullptr;
+   bool owns_index = true;
+   gm::IndexDev ix{};
+   void *d_occ = nullptr, *d_tables = nullptr, *d_sa = nullptr;
+   int64_t occ_bytes = 0, tables_bytes = 0, sa_bytes = 0;
+   int64_t sar_len = 0, tables_words = 0;
+   uint8_t sym_table[256];
+   uint8_t com_table[8];
+   uint8_t *d_sym_table = nullptr;
+   // reference-layout arrays kept on the device by gpumap_build_device (keep_reference != 0)
+   void *d_ref_occ = nullptr, *d_text = nullptr;
+   int64_t ref_occ_words = 0;
+   uint64_t c_host[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+   int64_t wil_cnt = 0;
+   // launch shape
+   int cu_count = 256;
+   int waves_per_cu = 0;              // 0 = the variant's default
+   int variant = 1;                   // 0 = k_search (node per quad), 1 = k_search_lane (node per lane)
+   int64_t spill_cap = 16384;         // nodes per wave
+   // scratch kept across runs
+   DevBuf spill, counters, op_in, op_out, cub_tmp;
+};
+
+
+// Repack of a reference-layout Occ array that already lies in device memory (d_ref_occ, d_c) into
+// the rank blocks and tables of ctx (allocated here); also copies seq_beg (host) behind the tables.
+// ctx->ix.n, sar fields and d_sa must be set by the caller.  gm_device.hip.
+int gm_ctx_repack(gpumap_ctx *ctx, const uint64_t *d_ref_occ, const uint64_t *d_c, int64_t mark_intv,
+                  const int64_t *seq_beg_host, int64_t seq_cnt);
+int gm_ctx_common_init(gpumap_ctx *ctx, int device);

@@ -7,66 +7,11 @@
 #include <cstring>
 #include <string>
 #include <vector>
-#include "gm_host.hpp"
+#include "gm_devctx.hpp"
 #include "gm_kernels.hpp"
 #include "gm_search_lane.hpp"
 
 using namespace gm;
-
-#define HIP_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
-   std::fprintf(stderr, "%s\t(%s:%d) error: %s: %s\n", __func__, __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
-   errno = 1; goto failure_return; } } while (0)
-
-namespace {
-
-struct DevBuf {
-   void *p = nullptr;
-   size_t cap = 0;
-   hipError_t ensure(size_t bytes)
-   {
-      if (bytes <= cap) return hipSuccess;
-      if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
-      size_t want = bytes + bytes / 4 + 256;
-      hipError_t e = hipMalloc(&p, want);
-      if (e != hipSuccess) { e = hipMalloc(&p, bytes); want = bytes; }
-      if (e == hipSuccess) cap = want;
-      return e;
-   }
-   void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
-   template <class T> T *as() const { return reinterpret_cast<T *>(p); }
-};
-
-struct DevIndexHeader {          // host blob that travels with an exported device index
-   uint64_t magic;
-   int64_t  n, n_blocks, n_super, sar_bits, sar_len, seq_cnt, tables_words;
-   uint8_t  sym_table[256];
-   uint8_t  com_table[8];
-};
-constexpr uint64_t DEVINDEX_MAGIC = 0x47504d4158444e49ULL;
-
-inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
-
-}  // namespace
-
-struct gpumap_ctx {
-   int device = 0;
-   hipStream_t stream = nullptr;
-   bool owns_index = true;
-   IndexDev ix{};
-   void *d_occ = nullptr, *d_tables = nullptr, *d_sa = nullptr;
-   int64_t occ_bytes = 0, tables_bytes = 0, sa_bytes = 0;
-   int64_t sar_len = 0, tables_words = 0;
-   uint8_t sym_table[256];
-   uint8_t com_table[8];
-   uint8_t *d_sym_table = nullptr;
-   // launch shape
-   int cu_count = 256;
-   int waves_per_cu = 0;              // 0 = the variant's default
-   int variant = 1;                   // 0 = k_search (node per quad), 1 = k_search_lane (node per lane)
-   int64_t spill_cap = 16384;         // nodes per wave
-   // scratch kept across runs
-   DevBuf spill, counters, op_in, op_out, cub_tmp;
-};
 
 struct gpumap_batch {
    gpumap_ctx *ctx = nullptr;
@@ -99,7 +44,7 @@ struct gpumap_batch {
 // Context
 // ------------------------------------------------------------------------------------------------
 
-static int ctx_common_init(gpumap_ctx *ctx, int device)
+int gm_ctx_common_init(gpumap_ctx *ctx, int device)
 {
    hipDeviceProp_t prop;
    HIP_TRY(hipSetDevice(device));
@@ -126,10 +71,50 @@ extern "C" void gpumap_destroy(gpumap_ctx *ctx)
       if (ctx->d_tables) (void)hipFree(ctx->d_tables);
       if (ctx->d_sa) (void)hipFree(ctx->d_sa);
    }
+   if (ctx->d_ref_occ) (void)hipFree(ctx->d_ref_occ);
+   if (ctx->d_text) (void)hipFree(ctx->d_text);
    if (ctx->d_sym_table) (void)hipFree(ctx->d_sym_table);
    for (DevBuf *b : {&ctx->spill, &ctx->counters, &ctx->op_in, &ctx->op_out, &ctx->cub_tmp}) b->release();
    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
    delete ctx;
+}
+
+int gm_ctx_repack(gpumap_ctx *ctx, const uint64_t *d_ref_occ, const uint64_t *d_c, int64_t mark_intv,
+                  const int64_t *seq_beg_host, int64_t seq_cnt)
+{
+   IndexDev &ix = ctx->ix;
+   GM_FAIL_IF(num_supers(ix.n) > MAX_SB_LDS, "text too long for the staged superblock table.");
+   ix.n_blocks = num_blocks(ix.n);
+   ix.n_super = num_supers(ix.n);
+   ix.seq_cnt = (int32_t)seq_cnt;
+   ctx->occ_bytes = ix.n_blocks * 64;
+   ctx->tables_words = TAB_SBASE + SYMS * ix.n_super + seq_cnt;
+   ctx->tables_bytes = ctx->tables_words * 8;
+   HIP_TRY(hipMalloc(&ctx->d_occ, (size_t)ctx->occ_bytes));
+   HIP_TRY(hipMalloc(&ctx->d_tables, (size_t)ctx->tables_bytes));
+   HIP_TRY(hipMemset(ctx->d_tables, 0, (size_t)ctx->tables_bytes));
+   {
+      int64_t n_ref_words = cdiv(ix.n, mark_intv * 64) * mark_intv;
+      int64_t g1 = cdiv(std::max<int64_t>(ix.n_super, SYMS), 64);
+      hipLaunchKernelGGL(k_super_counts, dim3((unsigned)g1), dim3(64), 0, ctx->stream, d_ref_occ,
+                         mark_intv, ix.n, ix.n_super, d_c, (uint64_t *)ctx->d_tables);
+      PackArgs P;
+      P.ref_occ = d_ref_occ; P.tables = (const uint64_t *)ctx->d_tables; P.blocks = (uint32_t *)ctx->d_occ;
+      P.intv = mark_intv; P.n_ref_words = n_ref_words; P.n_blocks = ix.n_blocks;
+      hipLaunchKernelGGL(k_pack_blocks, dim3((unsigned)cdiv(ix.n_blocks, 256)), dim3(256), 0, ctx->stream, P);
+   }
+   HIP_TRY(hipGetLastError());
+   // seq_beg sits behind the superblock table
+   HIP_TRY(hipMemcpyAsync((uint64_t *)ctx->d_tables + TAB_SBASE + SYMS * ix.n_super, seq_beg_host,
+                          8 * (size_t)seq_cnt, hipMemcpyHostToDevice, ctx->stream));
+   HIP_TRY(hipStreamSynchronize(ctx->stream));
+   ix.occ = (const uint32_t *)ctx->d_occ;
+   ix.tables = (const uint64_t *)ctx->d_tables;
+   ix.sa = (const uint64_t *)ctx->d_sa;
+   ix.seq_beg = (const int64_t *)((const uint64_t *)ctx->d_tables + TAB_SBASE + SYMS * ix.n_super);
+   return 0;
+failure_return:
+   return -1;
 }
 
 extern "C" gpumap_ctx *gpumap_create(const gpumap_index_view *v, int device)
@@ -144,7 +129,6 @@ extern "C" gpumap_ctx *gpumap_create(const gpumap_index_view *v, int device)
    GM_FAIL_IF(v->txt_len < 2 || v->txt_len >= ((int64_t)1 << 40), "text length out of range.");
    GM_FAIL_IF(v->sar_bits < 1 || v->sar_bits > 40, "sar_bits out of range.");
    GM_FAIL_IF(v->seq_cnt < 1 || v->seq_beg == nullptr, "index view has no sequences.");
-   GM_FAIL_IF(num_supers(v->txt_len) > MAX_SB_LDS, "text too long for the staged superblock table.");
    {
       // the Occ array must be exactly as long as bwt_build_opt makes it (src/index_bwt.c:501-507)
       int64_t mark_bits = v->occ_mark_intv * 64;
@@ -157,21 +141,13 @@ extern "C" gpumap_ctx *gpumap_create(const gpumap_index_view *v, int device)
    ctx = new gpumap_ctx();
    memcpy(ctx->sym_table, v->sym_table, 256);
    memcpy(ctx->com_table, v->com_table, SYMS + 1);
-   GM_FAIL_IF(ctx_common_init(ctx, device) != 0, "cannot initialise the device context.");
+   GM_FAIL_IF(gm_ctx_common_init(ctx, device) != 0, "cannot initialise the device context.");
    {
       IndexDev &ix = ctx->ix;
       ix.n = v->txt_len;
-      ix.n_blocks = num_blocks(ix.n);
-      ix.n_super = num_supers(ix.n);
       ix.sar_bits = (int32_t)v->sar_bits;
-      ix.seq_cnt = (int32_t)v->seq_cnt;
       ctx->sar_len = v->sar_len;
-      ctx->occ_bytes = ix.n_blocks * 64;
       ctx->sa_bytes = (v->sar_len + 1) * 8;           // one spare word: an entry read may touch word+1
-      ctx->tables_words = TAB_SBASE + SYMS * ix.n_super + v->seq_cnt;
-      ctx->tables_bytes = ctx->tables_words * 8;
-      HIP_TRY(hipMalloc(&ctx->d_occ, (size_t)ctx->occ_bytes));
-      HIP_TRY(hipMalloc(&ctx->d_tables, (size_t)ctx->tables_bytes));
       HIP_TRY(hipMalloc(&ctx->d_sa, (size_t)ctx->sa_bytes));
       HIP_TRY(hipMemset(ctx->d_sa, 0, (size_t)ctx->sa_bytes));
       HIP_TRY(hipMemcpy(ctx->d_sa, v->sa, (size_t)v->sar_len * 8, hipMemcpyHostToDevice));
@@ -180,28 +156,12 @@ extern "C" gpumap_ctx *gpumap_create(const gpumap_index_view *v, int device)
       HIP_TRY(hipMemcpy(d_ref, v->occ, (size_t)v->occ_length * 8, hipMemcpyHostToDevice));
       HIP_TRY(hipMalloc(&d_c, 8 * (SYMS + 1)));
       HIP_TRY(hipMemcpy(d_c, v->c, 8 * (SYMS + 1), hipMemcpyHostToDevice));
-      HIP_TRY(hipMemset(ctx->d_tables, 0, (size_t)ctx->tables_bytes));
-      int64_t n_ref_words = cdiv(ix.n, v->occ_mark_intv * 64) * v->occ_mark_intv;
-      int64_t g1 = cdiv(std::max<int64_t>(ix.n_super, SYMS), 64);
-      hipLaunchKernelGGL(k_super_counts, dim3((unsigned)g1), dim3(64), 0, ctx->stream, (const uint64_t *)d_ref,
-                         v->occ_mark_intv, ix.n, ix.n_super, (const uint64_t *)d_c, (uint64_t *)ctx->d_tables);
-      {
-         PackArgs P;
-         P.ref_occ = (const uint64_t *)d_ref; P.tables = (const uint64_t *)ctx->d_tables; P.blocks = (uint32_t *)ctx->d_occ;
-         P.intv = v->occ_mark_intv; P.n_ref_words = n_ref_words; P.n_blocks = ix.n_blocks;
-         hipLaunchKernelGGL(k_pack_blocks, dim3((unsigned)cdiv(ix.n_blocks, 256)), dim3(256), 0, ctx->stream, P);
-      }
-      HIP_TRY(hipGetLastError());
-      // seq_beg sits behind the superblock table
-      HIP_TRY(hipMemcpyAsync((uint64_t *)ctx->d_tables + TAB_SBASE + SYMS * ix.n_super, v->seq_beg,
-                             8 * (size_t)v->seq_cnt, hipMemcpyHostToDevice, ctx->stream));
-      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      GM_FAIL_IF(gm_ctx_repack(ctx, (const uint64_t *)d_ref, (const uint64_t *)d_c, v->occ_mark_intv, v->seq_beg, v->seq_cnt) != 0,
+                 "cannot repack the Occ table.");
       HIP_TRY(hipFree(d_ref)); d_ref = nullptr;
       HIP_TRY(hipFree(d_c)); d_c = nullptr;
-      ix.occ = (const uint32_t *)ctx->d_occ;
-      ix.tables = (const uint64_t *)ctx->d_tables;
-      ix.sa = (const uint64_t *)ctx->d_sa;
-      ix.seq_beg = (const int64_t *)((const uint64_t *)ctx->d_tables + TAB_SBASE + SYMS * ix.n_super);
+      memcpy(ctx->c_host, v->c, 8 * (SYMS + 1));
+      ctx->wil_cnt = v->wil_cnt;
    }
    (void)d_seq;
    return ctx;
@@ -265,7 +225,7 @@ extern "C" gpumap_ctx *gpumap_create_from_device(const gpumap_devindex *dev, con
    ctx->owns_index = false;
    memcpy(ctx->sym_table, h.sym_table, 256);
    memcpy(ctx->com_table, h.com_table, 8);
-   GM_FAIL_IF(ctx_common_init(ctx, device) != 0, "cannot initialise the device context.");
+   GM_FAIL_IF(gm_ctx_common_init(ctx, device) != 0, "cannot initialise the device context.");
    ctx->d_occ = dev->occ_blocks; ctx->d_sa = dev->sa_words; ctx->d_tables = dev->tables;
    ctx->occ_bytes = dev->occ_bytes; ctx->sa_bytes = dev->sa_bytes; ctx->tables_bytes = dev->tables_bytes;
    ctx->sar_len = h.sar_len; ctx->tables_words = h.tables_words;

@@ -20,6 +20,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "gm_core.hpp"
+#include "gm_devctx.hpp"
 
 namespace gm {
 
@@ -27,23 +28,6 @@ constexpr int WG_WAVES = 4;
 constexpr int WG_THREADS = 64 * WG_WAVES;
 constexpr int QCAP = 256;            // deque capacity per wave (nodes), power of two
 constexpr int SPILL_CHUNK = 128;     // nodes moved per spill / reload
-constexpr int MAX_SB_LDS = 256;      // superblocks whose counts are staged in LDS (n < 2^33)
-
-// Layout of the small `tables` buffer (64-bit words): [0..4] C[0..4]; [8 + 5*s + j] absolute count
-// of symbol j in BWT[0, s << 25).
-constexpr int TAB_C = 0;
-constexpr int TAB_SBASE = 8;
-
-struct IndexDev {
-   const uint32_t *occ;        // rank blocks, 16 dwords each
-   const uint64_t *tables;
-   const uint64_t *sa;         // packed suffix array, verbatim
-   const int64_t  *seq_beg;
-   int64_t n;                  // text length
-   int64_t n_blocks, n_super;
-   int32_t sar_bits;
-   int32_t seq_cnt;
-};
 
 // ------------------------------------------------------------------------------------------------
 // K0: repack
