@@ -38,6 +38,14 @@ WORKLOADS = {
                   desc="config 2 stand-in: 4.64 Mbp random (E. coli K-12 size), 1M x 100 nt, <=2 mismatches"),
     "chr21": dict(L=46_709_983, n_seqs=1, rich=True, gc=0.41, seed=3, reads=10_000_000, m=100, tau=2,
                   desc="config 3 stand-in: 46.7 Mbp repeat-rich (chr21 size), 10M x 100 nt, <=2 mismatches"),
+    # GRCh38 size: generated and indexed in HBM (mapper_amd/synth_device.py, gpumap_build_device); the reads of
+    # config 4 (100 M) are the 8-GPU total, 12.5 M per GPU (weak scaling: the per-GPU batch is fixed)
+    "grch38": dict(L=3_100_000_000, n_seqs=24, rich=True, gc=0.41, seed=4, reads=12_500_000, m=100, tau=2, device=True,
+                   desc="config 4 stand-in: 3.1 Gbp repeat-rich in 24 sequences (GRCh38 size), 12.5M x 100 nt per GPU, <=2 mismatches"),
+    "grch38_150": dict(L=3_100_000_000, n_seqs=24, rich=True, gc=0.41, seed=4, reads=4_000_000, m=150, tau=4, device=True,
+                       desc="config 5 stand-in: GRCh38-size index, 4M x 150 nt per GPU, <=4 mismatches"),
+    "g1": dict(L=1_000_000_000, n_seqs=8, rich=True, gc=0.41, seed=5, reads=12_500_000, m=100, tau=2, device=True,
+               desc="1 Gbp repeat-rich in 8 sequences, 12.5M x 100 nt per GPU, <=2 mismatches"),
 }
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 BYTES_PER_EXT = 128.0           # two 64-B Occ touches per extension step
@@ -56,11 +64,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default=os.environ.get("GPUMAP_WORKLOAD", "chr21"))
+    ap.add_argument("--workload", default=os.environ.get("GPUMAP_WORKLOAD", "grch38"))
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU (0 = the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--waves-per-cu", type=int, default=0)
+    ap.add_argument("--device-build", action="store_true", help="generate and index in HBM also for the small workloads")
     args = ap.parse_args()
 
     import torch
@@ -82,20 +91,35 @@ def main():
     w = dict(WORKLOADS[args.workload])
     if args.reads:
         w["reads"] = args.reads
+    on_device = bool(w.get("device")) or args.device_build
     t_setup = time.time()
-    # every rank regenerates the same synthetic sequences (deterministic) to draw its reads from
-    seqs, names = synth.make_genome(w["L"], w["seed"], n_seqs=w["n_seqs"], gc=w["gc"], repeat_rich=w["rich"])
     tmp = tempfile.mkdtemp(prefix="gpumap_bench_")
     base = os.path.join(tmp, args.workload)
     keep = []
     t_index = t_upload = t_bcast = 0.0
-    if rank == 0:
-        t0 = time.time()
-        hix = ma.HostIndex.build_codes(seqs, names, base)       # also writes base.* for the CPU baseline
-        t_index = time.time() - t0
-        t0 = time.time()
-        ctx = ma.Context.from_index(hix, local)
-        t_upload = time.time() - t0
+    want_cpu = not args.no_cpu_baseline and world == 1
+    read_seed = w["seed"] * 1000 + 17 + rank
+    if on_device:
+        from mapper_amd import synth_device
+        # every rank generates the same synthetic sequences in its own HBM to draw its reads from
+        g, lens, names = synth_device.make_genome(w["L"], w["seed"], n_seqs=w["n_seqs"], gc=w["gc"], repeat_rich=w["rich"])
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        if rank == 0:
+            t0 = time.time()
+            ctx = ma.Context.build_device(lens, local, keep_reference=want_cpu, device_ptr=g.data_ptr())
+            t_index = time.time() - t0
+        seqs = None
+    else:
+        # every rank regenerates the same synthetic sequences (deterministic) to draw its reads from
+        seqs, names = synth.make_genome(w["L"], w["seed"], n_seqs=w["n_seqs"], gc=w["gc"], repeat_rich=w["rich"])
+        if rank == 0:
+            t0 = time.time()
+            hix = ma.HostIndex.build_codes(seqs, names, base)       # also writes base.* for the CPU baseline
+            t_index = time.time() - t0
+            t0 = time.time()
+            ctx = ma.Context.from_index(hix, local)
+            t_upload = time.time() - t0
     if world > 1:
         # one-off replication of the device-resident index: RCCL broadcast over xGMI
         t0 = time.time()
@@ -124,7 +148,14 @@ def main():
         ctx.set_option("waves_per_cu", args.waves_per_cu)
 
     # this rank's shard: its own reads (weak scaling), resident in HBM before the timed region
-    codes, offs = synth.make_reads(seqs, w["reads"], w["m"], w["tau"], seed=w["seed"] * 1000 + 17 + rank)
+    if on_device:
+        rd = synth_device.make_reads(g, lens, w["reads"], w["m"], w["tau"], seed=read_seed)
+        codes = rd.cpu().numpy()
+        offs = np.arange(w["reads"] + 1, dtype=np.int64) * w["m"]
+        del rd, g
+        torch.cuda.empty_cache()
+    else:
+        codes, offs = synth.make_reads(seqs, w["reads"], w["m"], w["tau"], seed=read_seed)
     batch = ctx.upload(codes.reshape(-1), offs)
     t_setup = time.time() - t_setup
 
@@ -172,11 +203,11 @@ def main():
             "hits_per_batch": {"intervals": c["n_hits"], "located": c["n_locs"]},
             "occupancy": {"loop_passes": c["loop_passes"], "child_passes": c["child_passes"],
                           "lane_fill": (c["n_ext"] / (64.0 * c["loop_passes"])) if c["loop_passes"] else None},
-            "setup_s": {"index_build_host": t_index, "upload_repack": t_upload, "rccl_broadcast": t_bcast,
+            "setup_s": {"index_build": t_index, "index_built_on": "device" if on_device else "host", "upload_repack": t_upload, "rccl_broadcast": t_bcast,
                         "all": t_setup},
         }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(base, codes, offs, w, args.cpu_seconds)
+        if want_cpu:
+            out["cpu_baseline"] = cpu_baseline(ctx if on_device else None, base, codes, offs, w, args.cpu_seconds, gpu_ctx=ctx)
         print(json.dumps(out), flush=True)
     batch.close()
     if world > 1:
@@ -186,20 +217,32 @@ def main():
     del keep
 
 
-def cpu_baseline(base, codes, offs, w, seconds):
+def cpu_baseline(ctx, base, codes, offs, w, seconds, gpu_ctx=None):
     """The oracle's C restatement (kind "port") on the host cores, on a bounded sample of the same
-    reads against the same index files.  Test infrastructure used as the baseline only."""
+    reads against the same index (the files the host builder wrote, or the reference-layout arrays of
+    a device build copied back).  Test infrastructure used as the baseline only."""
     from oracle import pyoracle as po
-    orc = po.Index(base)
+    if ctx is None:
+        orc = po.Index(base)
+    else:
+        ref = ctx.reference_arrays(want_text=False)
+        orc = po.Index.from_arrays(ref["occ"], ref["c"], ref["sa"], ref["sar_bits"], ref["txt_len"], ref["wil_cnt"])
     cores = min(16, os.cpu_count() or 1)
     probe = min(len(offs) - 1, 4000 * cores)
     d = orc.map_batch(codes[:probe].reshape(-1), offs[:probe + 1], w["tau"], threads=cores)
     rate = probe / max(d.seconds, 1e-6)
     n = int(min(len(offs) - 1, max(probe, rate * seconds)))
     d = orc.map_batch(codes[:n].reshape(-1), offs[:n + 1], w["tau"], threads=cores)
-    return {"value": n / d.seconds, "unit": "reads/s", "cores": cores, "kind": "port",
-            "sample": "first %d reads of the batch, %d pthreads, %.1f s" % (n, cores, d.seconds),
-            "ext_steps_per_read": d.n_ext / n}
+    out = {"value": n / d.seconds, "unit": "reads/s", "cores": cores, "kind": "port",
+           "sample": "first %d reads of the batch, %d pthreads, %.1f s" % (n, cores, d.seconds),
+           "ext_steps_per_read": d.n_ext / n}
+    if gpu_ctx is not None:
+        # the same sample through the HIP path: mapped positions, strands (position >= n/2) and scores must be identical
+        h = gpu_ctx.map_batch(codes[:n].reshape(-1), offs[:n + 1], w["tau"])
+        out["parity_on_sample"] = {"reads": n, "located": int(h.n_locs),
+                                   "identical": bool(np.array_equal(h.status, d.status) and
+                                                     np.array_equal(h.located(), d.located()) and h.n_ext == d.n_ext)}
+    return out
 
 
 if __name__ == "__main__":

@@ -123,26 +123,32 @@ __global__ void k_segment_apply(const u64 *idx, const u64 *rs, int64_t m, int64_
 }
 
 // Stable compaction of the flagged positions: out = in[x] (or x itself when in == nullptr).
-__global__ void __launch_bounds__(1024) k_flag_count(const uint8_t *flag, int64_t n, u64 *cnt)
+// (A launch holds fewer than 2^32 threads, texts more than 2^32 symbols: chunks of 1024 are looped over.)
+__global__ void __launch_bounds__(1024) k_flag_count(const uint8_t *flag, int64_t n, int64_t n_chunks, u64 *cnt)
 {
-   int64_t x = blockIdx.x * (int64_t)1024 + threadIdx.x;
-   int c = __syncthreads_count(x < n && flag[x]);
-   if (threadIdx.x == 0) cnt[blockIdx.x] = (u64)c;
+   for (int64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+      int64_t x = ch * 1024 + threadIdx.x;
+      int c = __syncthreads_count(x < n && flag[x]);
+      if (threadIdx.x == 0) cnt[ch] = (u64)c;
+   }
 }
 
-__global__ void __launch_bounds__(1024) k_flag_write(const uint8_t *flag, int64_t n, const u64 *off, const u64 *in, u64 *out)
+__global__ void __launch_bounds__(1024) k_flag_write(const uint8_t *flag, int64_t n, int64_t n_chunks, const u64 *off, const u64 *in, u64 *out)
 {
    __shared__ unsigned int wcnt[16];
    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-   int64_t x = blockIdx.x * (int64_t)1024 + threadIdx.x;
-   bool f = x < n && flag[x];
-   u64 m = __ballot(f);
-   if (lane == 0) wcnt[wid] = (unsigned int)__popcll(m);
-   __syncthreads();
-   if (f) {
-      unsigned int before = 0;
-      for (int w = 0; w < wid; w++) before += wcnt[w];
-      out[off[blockIdx.x] + before + (u64)__popcll(m & ((1ull << lane) - 1ull))] = in ? in[x] : (u64)x;
+   for (int64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+      int64_t x = ch * 1024 + threadIdx.x;
+      bool f = x < n && flag[x];
+      u64 m = __ballot(f);
+      if (lane == 0) wcnt[wid] = (unsigned int)__popcll(m);
+      __syncthreads();
+      if (f) {
+         unsigned int before = 0;
+         for (int w = 0; w < wid; w++) before += wcnt[w];
+         out[off[ch] + before + (u64)__popcll(m & ((1ull << lane) - 1ull))] = in ? in[x] : (u64)x;
+      }
+      __syncthreads();
    }
 }
 
@@ -247,6 +253,26 @@ __global__ void k_pack_sa(const u64 *sa, int64_t n, int bits, int64_t words, u64
    }
 }
 
+// Debug aid (GPUMAP_BUILD_VERIFY=samples): neighbours in the suffix array must be in suffix order.
+__global__ void k_verify_order(const uint8_t *text, const u64 *sa, int64_t n, int64_t samples, u64 *bad)
+{
+   int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+   if (t >= samples) return;
+   u64 z = (u64)t * 0x9E3779B97F4A7C15ull + 0x1234567ull;
+   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+   int64_t i = (int64_t)(z % (u64)(n - 1));
+   int64_t a = (int64_t)sa[i], b = (int64_t)sa[i + 1];
+   if (a < 0 || a >= n || b < 0 || b >= n || a == b) { atomicAdd(bad, 1ull); return; }
+   for (;;) {
+      if (a >= n) return;                       // the shorter suffix sorts first
+      if (b >= n) { atomicAdd(bad, 1ull); return; }
+      int x = shifted(text[a]), y = shifted(text[b]);
+      if (x < y) return;
+      if (x > y) { atomicAdd(bad, 1ull); return; }
+      a++; b++;
+   }
+}
+
 struct Arena {       // device allocations of the build, released together
    std::vector<void *> p;
    template <class T> hipError_t get(T **out, size_t count)
@@ -312,14 +338,15 @@ int compact(const uint8_t *flag, int64_t n, const u64 *in, u64 **out, int64_t *c
    *out = nullptr; *count = 0;
    HIP_TRY(A.get(&cnt, (size_t)nb));
    HIP_TRY(A.get(&off, (size_t)nb));
-   hipLaunchKernelGGL(k_flag_count, dim3((unsigned)nb), dim3(1024), 0, st, flag, n, cnt);
+   hipLaunchKernelGGL(k_flag_count, dim3(grid_for(nb, 1)), dim3(1024), 0, st, flag, n, nb, cnt);
+   HIP_TRY(hipGetLastError());
    HIP_TRY(scan_sum(cnt, off, nb, false, tmp, st));
    HIP_TRY(hipMemcpyAsync(&last[0], off + nb - 1, 8, hipMemcpyDeviceToHost, st));
    HIP_TRY(hipMemcpyAsync(&last[1], cnt + nb - 1, 8, hipMemcpyDeviceToHost, st));
    HIP_TRY(hipStreamSynchronize(st));
    *count = (int64_t)(last[0] + last[1]);
    HIP_TRY(A.get(out, (size_t)*count));
-   if (*count > 0) hipLaunchKernelGGL(k_flag_write, dim3((unsigned)nb), dim3(1024), 0, st, flag, n, (const u64 *)off, in, *out);
+   if (*count > 0) hipLaunchKernelGGL(k_flag_write, dim3(grid_for(nb, 1)), dim3(1024), 0, st, flag, n, nb, (const u64 *)off, in, *out);
    HIP_TRY(hipGetLastError());
    HIP_TRY(hipStreamSynchronize(st));
    A.drop(cnt); A.drop(off);
@@ -336,7 +363,7 @@ int suffix_sort_device(const uint8_t *text, int64_t n, u64 *sa, hipStream_t st, 
    u64 *rk = nullptr, *hist = nullptr, *cursor = nullptr, *pos = nullptr;
    uint8_t *unres = nullptr;
    int64_t U = 0;
-   const int P = n >= ((int64_t)1 << 30) ? 2 : 1;
+   const int P = getenv("GPUMAP_BUILD_P") ? std::min(2, std::max(1, atoi(getenv("GPUMAP_BUILD_P")))) : (n >= ((int64_t)1 << 30) ? 2 : 1);
    const int n_class = 1 << (3 * P);
    const bool force_two_pass = getenv("GPUMAP_BUILD_TWO_PASS") != nullptr;
    u64 h_hist[64];
@@ -483,6 +510,17 @@ extern "C" gpumap_ctx *gpumap_build_device(const uint8_t *codes, int codes_on_de
       u64 *sa = nullptr;
       HIP_TRY(A.get(&sa, (size_t)n));
       GM_FAIL_IF(suffix_sort_device(text, n, sa, st, verbose) != 0, "suffix sort failed.");
+      if (const char *e = getenv("GPUMAP_BUILD_VERIFY")) {
+         const int64_t samples = std::max<int64_t>(1, atoll(e));
+         u64 *bad = nullptr, h_bad = 0;
+         HIP_TRY(A.get(&bad, 1));
+         HIP_TRY(hipMemsetAsync(bad, 0, 8, st));
+         hipLaunchKernelGGL(k_verify_order, dim3((unsigned)cdiv(samples, 256)), dim3(256), 0, st, (const uint8_t *)text, (const u64 *)sa, n, samples, bad);
+         HIP_TRY(hipMemcpyAsync(&h_bad, bad, 8, hipMemcpyDeviceToHost, st));
+         HIP_TRY(hipStreamSynchronize(st));
+         fprintf(stderr, "[gpumap build] verify: %llu of %ld sampled neighbours out of order\n", h_bad, (long)samples);
+         GM_FAIL_IF(h_bad != 0, "suffix array is not sorted.");
+      }
       // ---- Occ array in the reference's layout, C[]
       const int64_t n_intv = cdiv(n, MARK_INTV * 64), n_word = n_intv * MARK_INTV;
       const int64_t occ_words = (n_word + n_intv + 1) * SYMS;

@@ -351,7 +351,7 @@ extern "C" int gpumap_encode(gpumap_ctx *ctx, const char *text, const int64_t *o
       HIP_TRY(ctx->op_in.ensure((size_t)total));
       HIP_TRY(ctx->op_out.ensure((size_t)total));
       HIP_TRY(hipMemcpyAsync(ctx->op_in.p, text + offsets[0], (size_t)total, hipMemcpyHostToDevice, ctx->stream));
-      hipLaunchKernelGGL(k_encode_flat, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, ctx->stream,
+      hipLaunchKernelGGL(k_encode_flat, dim3((unsigned)std::min<int64_t>(cdiv(total, 256), 1 << 22)), dim3(256), 0, ctx->stream,
                          ctx->op_in.as<const uint8_t>(), total, (const uint8_t *)ctx->d_sym_table, ctx->op_out.as<uint8_t>());
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipMemcpyAsync(codes + offsets[0], ctx->op_out.p, (size_t)total, hipMemcpyDeviceToHost, ctx->stream));
@@ -409,7 +409,7 @@ static gpumap_batch *batch_upload(gpumap_ctx *ctx, const uint8_t *src, const int
          for (int64_t r = 0; r <= n_reads; r++) rel[r] = offsets[r] - offsets[0];
          HIP_TRY(hipMemcpyAsync(d_off.p, rel.data(), 8 * (size_t)(n_reads + 1), hipMemcpyHostToDevice, ctx->stream));
          int64_t threads = n_reads * b->stride;
-         hipLaunchKernelGGL(k_encode, dim3((unsigned)cdiv(threads, 256)), dim3(256), 0, ctx->stream,
+         hipLaunchKernelGGL(k_encode, dim3((unsigned)std::min<int64_t>(cdiv(threads, 256), 1 << 22)), dim3(256), 0, ctx->stream,
                             d_src.as<const uint8_t>(), d_off.as<const int64_t>(), n_reads, b->stride,
                             is_text ? (const uint8_t *)ctx->d_sym_table : (const uint8_t *)nullptr,
                             b->reads.as<uint8_t>(), b->read_len.as<uint16_t>(), (uint8_t *)nullptr);

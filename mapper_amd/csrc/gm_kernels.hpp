@@ -162,26 +162,27 @@ __global__ void k_encode(const uint8_t *src, const int64_t *offsets, int64_t n_r
                          const uint8_t *table /* 256 entries, or nullptr for codes */, uint8_t *dst,
                          uint16_t *read_len, uint8_t *flat_codes /* optional, same layout as src */)
 {
-   int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-   int64_t r = t / stride;
-   int p = (int)(t - r * stride);
-   if (r >= n_reads) return;
-   int64_t beg = offsets[r], len = offsets[r + 1] - beg;
-   if (p == 0) read_len[r] = (uint16_t)(len < 0 ? 0 : (len > 0xffff ? 0xffff : len));
-   uint8_t code = 0xff;
-   if (p < len) {
-      uint8_t s = src[beg + p];
-      code = table ? table[s] : (s < SYMS ? s : (uint8_t)UNKNOWN);
-      if (flat_codes) flat_codes[beg + p] = code;
+   // grid-stride: a launch holds fewer than 2^32 threads, a batch may hold more letters
+   for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n_reads * stride; t += (int64_t)gridDim.x * blockDim.x) {
+      int64_t r = t / stride;
+      int p = (int)(t - r * stride);
+      int64_t beg = offsets[r], len = offsets[r + 1] - beg;
+      if (p == 0) read_len[r] = (uint16_t)(len < 0 ? 0 : (len > 0xffff ? 0xffff : len));
+      uint8_t code = 0xff;
+      if (p < len) {
+         uint8_t s = src[beg + p];
+         code = table ? table[s] : (s < SYMS ? s : (uint8_t)UNKNOWN);
+         if (flat_codes) flat_codes[beg + p] = code;
+      }
+      dst[t] = code;
    }
-   dst[t] = code;
 }
 
 // Flat variant for gpumap_encode: sym_str_index (src/index_sym.c:293-319) over a whole buffer.
 __global__ void k_encode_flat(const uint8_t *src, int64_t n, const uint8_t *table, uint8_t *dst)
 {
-   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-   if (i < n) dst[i] = table[src[i]];
+   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+      dst[i] = table[src[i]];
 }
 
 // ------------------------------------------------------------------------------------------------

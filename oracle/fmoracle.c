@@ -108,6 +108,38 @@ fail:
    return NULL;
 }
 
+/* Index over arrays the caller owns, laid out as in the .bwt / .sar files (for indexes that never
+** existed as files: the GRCh38-size synthetic index of bench.py).  One unnamed sequence; the text
+** is optional (the search does not read it). */
+orc_index_t *orc_index_from_arrays(const uint64_t *occ, int64_t occ_length, int64_t mark_intv,
+                                   const uint64_t *c, const uint64_t *sa, int64_t sar_bits,
+                                   int64_t sar_len, int64_t txt_len, int64_t wil_cnt,
+                                   const uint8_t *text)
+{
+   static const int64_t zero = 0;
+   static const char *noname = "seq";
+   orc_index_t *x = calloc(1, sizeof *x);
+   if (!x) return NULL;
+   x->sym_cnt = 5;
+   memcpy(x->canon, "ACGTN", 6);
+   memset(x->sym_table, 4, 256);
+   {
+      const char *al[5] = {"Aa", "Cc", "Gg", "Tt", "Nn"};   /* src/index_sym.c:11 */
+      const uint8_t com[6] = {3, 2, 1, 0, 4, 5};             /* src/index_sym.c:12 */
+      for (int i = 0; i < 5; i++) for (const char *q = al[i]; *q; q++) x->sym_table[(uint8_t)*q] = (uint8_t)i;
+      memcpy(x->com_table, com, 6);
+   }
+   x->txt_len = txt_len; x->seq_cnt = 1; x->wil_cnt = wil_cnt; x->rc_flag = 1;
+   x->seq_len = &x->txt_len; x->seq_beg = &zero;
+   x->seq_name = calloc(1, sizeof(char *));
+   x->seq_name[0] = noname;
+   x->text = text;
+   x->sar_bits = sar_bits; x->sar_len = sar_len; x->sar_txt_len = txt_len; x->sa = sa;
+   x->occ_length = occ_length; x->mark_intv = mark_intv; x->word_size = 64; x->mark_bits = 64 * mark_intv;
+   x->c = c; x->occ = occ;
+   return x;
+}
+
 void orc_index_close(orc_index_t *x)
 {
    if (!x) return;

@@ -46,6 +46,11 @@ typedef struct {
 
 /* Index files base.{sym,txt,sar,bwt} in the reference's on-disk format. */
 orc_index_t *orc_index_open(const char *base);
+/* Same index over arrays in memory (same layouts as the files); the caller keeps them alive. */
+orc_index_t *orc_index_from_arrays(const uint64_t *occ, int64_t occ_length, int64_t mark_intv,
+                                   const uint64_t *c, const uint64_t *sa, int64_t sar_bits,
+                                   int64_t sar_len, int64_t txt_len, int64_t wil_cnt,
+                                   const uint8_t *text);
 void         orc_index_close(orc_index_t *idx);
 int64_t      orc_txt_length(const orc_index_t *idx);
 int64_t      orc_seq_count(const orc_index_t *idx);

@@ -47,6 +47,9 @@ def lib():
         L.orc_index_open.restype = C.c_void_p
         L.orc_index_open.argtypes = [C.c_char_p]
         L.orc_index_close.argtypes = [C.c_void_p]
+        L.orc_index_from_arrays.restype = C.c_void_p
+        L.orc_index_from_arrays.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
+                                            C.c_int64, C.c_int64, C.c_int64, C.c_void_p]
         for f in ("orc_txt_length", "orc_seq_count", "orc_sar_bits", "orc_wildcard_count"):
             getattr(L, f).restype = C.c_int64
             getattr(L, f).argtypes = [C.c_void_p]
@@ -130,9 +133,10 @@ class HitDump:
 
 
 class Index:
-    def __init__(self, base):
+    def __init__(self, base, _handle=None, _keep=None):
         self.base = base
-        self._h = lib().orc_index_open(base.encode())
+        self._keep = _keep
+        self._h = _handle if _handle is not None else lib().orc_index_open(base.encode())
         if not self._h:
             raise IOError("cannot open index %s" % base)
         self.txt_len = lib().orc_txt_length(self._h)
@@ -140,6 +144,17 @@ class Index:
         self.seq_cnt = lib().orc_seq_count(self._h)
         self.wil_cnt = lib().orc_wildcard_count(self._h)
         self.c = [int(lib().orc_c_array(self._h)[i]) for i in range(6)]
+
+    @classmethod
+    def from_arrays(cls, occ, c, sa, sar_bits, txt_len, wil_cnt, text=None, mark_intv=14):
+        """Index over numpy arrays laid out as in the .bwt / .sar (/.txt) files."""
+        occ = np.ascontiguousarray(occ, dtype=np.uint64)
+        c = np.ascontiguousarray(c, dtype=np.uint64)
+        sa = np.ascontiguousarray(sa).view(np.uint64)
+        h = lib().orc_index_from_arrays(occ.ctypes.data, len(occ), mark_intv, c.ctypes.data, sa.ctypes.data,
+                                        int(sar_bits), len(sa), int(txt_len), int(wil_cnt),
+                                        text.ctypes.data if text is not None else None)
+        return cls("<arrays>", _handle=h, _keep=(occ, c, sa, text))
 
     def close(self):
         if self._h:

@@ -54,10 +54,13 @@ def test_device_build_small_texts():
         _check(seqs).close()
 
 
-@pytest.mark.parametrize("two_pass", [False, True])
-def test_device_build_repeat_rich(two_pass, monkeypatch):
+@pytest.mark.parametrize("two_pass,classes", [(False, 1), (True, 1), (False, 2)])
+def test_device_build_repeat_rich(two_pass, classes, monkeypatch):
+    # the paths large texts take (two-pass group sort, classes of two leading symbols), forced at a small size
     if two_pass:
         monkeypatch.setenv("GPUMAP_BUILD_TWO_PASS", "1")
+    monkeypatch.setenv("GPUMAP_BUILD_P", str(classes))
+    monkeypatch.setenv("GPUMAP_BUILD_VERIFY", "100000")
     seqs, _ = synth.make_genome(400_000, 11, n_seqs=3, gc=0.41, repeat_rich=True)
     _check(seqs).close()
 
