@@ -186,6 +186,7 @@ def main():
         value = total_reads / elapsed
         k_ms = float(np.mean(ms_search))
         achieved = BYTES_PER_EXT * c["n_ext"] / (k_ms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(args.workload)
         out = {
             "metric": "reads mapped/sec (node), 100nt <=2 mm; % HBM gather roofline",
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -194,8 +195,8 @@ def main():
             "config": {"workload": args.workload, "description": w["desc"], "text_len": int(2 * (w["L"] + w["n_seqs"])),
                        "reads_per_gpu": w["reads"], "read_len": w["m"], "tau": w["tau"],
                        "parallelism": "reads sharded over %d GPU(s), index replicated (RCCL broadcast)" % world},
-            "roofline": {"bound": "hbm", "kernel": "k_search", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": "k_search_lane", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel_ms": k_ms, "ext_steps_per_launch": c["n_ext"],
                          "algorithmic_bytes_per_launch": BYTES_PER_EXT * c["n_ext"]},
             "stages_ms": {"search": c["ms_search"], "locate": c["ms_locate"], "order": c["ms_sort"],
@@ -215,6 +216,21 @@ def main():
         dist.destroy_process_group()
     ctx.close()
     del keep
+
+
+def pmc_traffic(workload):
+    """HBM-side bytes per launch of the search kernel from the committed rocprofv3 PMC passes of this same
+    command (tools/profile_passes.sh -> profiles/r1_<workload>_profile_summary.json): (FETCH_SIZE +
+    WRITE_SIZE) * 1024.  FETCH_SIZE = TCC_EA0_RDREQ * 64 B here (every request of this kernel is one
+    64-byte line, TCC_EA0_RDREQ_32B = 0), so the factor 2 of wide coalesced streams does not apply
+    (MI355X_MICROARCH.md, HBM).  None when no profile of this workload is committed."""
+    path = os.path.join(ROOT, "profiles", "r1_%s_profile_summary.json" % workload)
+    try:
+        pm = json.load(open(path))["pmc_per_launch"]
+        k = pm.get("gm::k_search_lane") or next(iter(pm.values()))
+        return (k["FETCH_SIZE"]["avg"] + k["WRITE_SIZE"]["avg"]) * 1024.0, os.path.relpath(path, ROOT)
+    except Exception:
+        return None, None
 
 
 def cpu_baseline(ctx, base, codes, offs, w, seconds, gpu_ctx=None):

@@ -54,7 +54,13 @@ def make_genome(total_len, seed, n_seqs=1, gc=0.41, repeat_rich=True, device="cu
             hit = torch.rand(k, fam_len, generator=gen, device=device) < div[:, None]
             shift = torch.randint(1, 4, (k, fam_len), generator=gen, device=device, dtype=torch.uint8)
             base = torch.where(hit, (base + shift) & 3, base)
-            g[(pos[:, None] + ar[None, :]).reshape(-1)] = base.reshape(-1)
+            # copies may overlap: the deterministic index_put keeps the data a function of the seed alone
+            prev = torch.are_deterministic_algorithms_enabled()
+            torch.use_deterministic_algorithms(True)
+            try:
+                g.index_put_(((pos[:, None] + ar[None, :]).reshape(-1),), base.reshape(-1))
+            finally:
+                torch.use_deterministic_algorithms(prev)
         n_arrays = max(1, int(0.02 * total_len / (171 * 1000)))
         monos = _random_bases(171 * n_arrays, gc, gen, device).view(n_arrays, 171)
         reps = 1000 if total_len > 400000 else max(2, total_len // (171 * 50))

@@ -3,18 +3,25 @@
 #   tools/profile_passes.sh OUTDIR WORKLOAD [extra bench args]
 # pass 0: --kernel-trace --stats; then one --pmc pass per counter group (never combined with traces).
 # Each pass is its own process with its own time limit; the script stops at the first failure.
+# Raw rocprofv3 output stays in /tmp (gpurun_out/ is limited to 64 MiB); summaries go to OUTDIR.
 out=$1; shift; wl=$1; shift
-mkdir -p $out
-cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
+final=$R/$out
+raw=/tmp/gpumap_prof_$$
+mkdir -p $final $raw
+cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --workload $wl --steps 2 --warmup 1 --no-cpu-baseline $*"
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/stats -- $B > $R/$out/stats.json 2> $R/$out/stats.err || { echo "stats pass failed"; tail -5 $R/$out/stats.err; exit 1; }
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $raw/stats -- $B > $raw/stats.json 2> $raw/stats.err || { echo "stats pass failed"; tail -5 $raw/stats.err; exit 1; }
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" \
            "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU" \
            "SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS" \
            "GRBM_GUI_ACTIVE TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum"; do
   i=$((i+1))
-  timeout -s KILL 300 rocprofv3 --pmc $grp --output-format csv -d $R/$out/pmc$i -- $B > $R/$out/pmc$i.json 2> $R/$out/pmc$i.err || { echo "pmc pass $i ($grp) failed"; tail -5 $R/$out/pmc$i.err; exit 1; }
+  timeout -s KILL 300 rocprofv3 --pmc $grp --output-format csv -d $raw/pmc$i -- $B > $raw/pmc$i.json 2> $raw/pmc$i.err || { echo "pmc pass $i ($grp) failed"; tail -5 $raw/pmc$i.err; exit 1; }
 done
-python3 $R/tools/profile_summary.py $R/$out > $R/$out/summary.json && cat $R/$out/summary.json
+python3 $R/tools/profile_summary.py $raw > $final/summary.json || exit 1
+cp $raw/stats/*/*kernel_stats.csv $final/kernel_stats.csv
+cp $raw/*.json $final/ 2>/dev/null
+for d in $raw/pmc*/; do n=$(basename $d); head -1 $d/*/*counter_collection.csv > $final/$n.counters.csv; grep k_search $d/*/*counter_collection.csv >> $final/$n.counters.csv; done
+cat $final/summary.json
