@@ -81,9 +81,11 @@ def make_genome(total_len, seed, n_seqs=1, gc=0.41, repeat_rich=True, device="cu
     return g, lens, names
 
 
-def make_reads(genome, lens, n_reads, read_len, max_mm, seed, n_frac=0.001):
+def make_reads(genome, lens, n_reads, read_len, max_mm, seed, n_frac=0.001, return_origin=False):
     """genome: uint8 cuda tensor (the sequences one after another), lens: their lengths.
-    Returns codes [n_reads][read_len] uint8 (cuda tensor)."""
+    Returns codes [n_reads][read_len] uint8 (cuda tensor); with return_origin also (start, strand):
+    the window's first position in the concatenated sequences and 1 where the read is its reverse
+    complement."""
     device = genome.device
     gen = _gen(seed, device)
     total = genome.numel()
@@ -91,6 +93,8 @@ def make_reads(genome, lens, n_reads, read_len, max_mm, seed, n_frac=0.001):
     ar = torch.arange(read_len, device=device)
     reads = torch.empty((n_reads, read_len), dtype=torch.uint8, device=device)
     todo = torch.arange(n_reads, device=device)
+    origin = torch.empty(n_reads, dtype=torch.int64, device=device)
+    strand = torch.zeros(n_reads, dtype=torch.uint8, device=device)
     step = 1 << 22
     while todo.numel():
         nxt = []
@@ -101,6 +105,7 @@ def make_reads(genome, lens, n_reads, read_len, max_mm, seed, n_frac=0.001):
             same_seq = torch.searchsorted(bounds, p, right=True) == torch.searchsorted(bounds, p + read_len - 1, right=True)
             good = same_seq & ~(w == 4).any(dim=1)          # windows with a text N are re-drawn (synth.py)
             reads[t[good]] = w[good]
+            origin[t[good]] = p[good]
             nxt.append(t[~good])
         todo = torch.cat(nxt)
     for lo in range(0, n_reads, step):
@@ -130,5 +135,6 @@ def make_reads(genome, lens, n_reads, read_len, max_mm, seed, n_frac=0.001):
         comp = torch.tensor([3, 2, 1, 0, 4], dtype=torch.uint8, device=device)
         sel = torch.nonzero(rc).flatten()
         r[sel] = comp[r[sel].flip(1).long()]
+        strand[lo + sel] = 1
         reads[lo:lo + k] = r
-    return reads
+    return (reads, origin, strand) if return_origin else reads

@@ -208,3 +208,28 @@ def test_synthetic_generators_are_deterministic():
     x = s.u64(10)
     s2 = synth.Stream(1)
     assert np.array_equal(np.concatenate([s2.u64(4), s2.u64(6)]), x)   # chunked == whole
+
+
+def test_device_generator_on_cpu_tensors():
+    """mapper_amd/synth_device.py with torch on the CPU: reads are windows of the sequences (reverse
+    complemented where strand = 1) with at most max_mm substitutions and the occasional N; windows never
+    span two sequences or contain a text N."""
+    import torch
+    from mapper_amd import synth_device
+    g, lens, names = synth_device.make_genome(300_000, 3, n_seqs=3, device="cpu")
+    assert g.numel() == 300_000 and int(lens.sum()) == 300_000 and len(names) == 3
+    g2, _, _ = synth_device.make_genome(300_000, 3, n_seqs=3, device="cpu")
+    assert torch.equal(g, g2)                                   # a function of the seed alone
+    assert int((g == 4).sum()) >= 300_000 // 40
+    reads, origin, strand = synth_device.make_reads(g, lens, 5000, 60, 2, seed=8, n_frac=0.05, return_origin=True)
+    gn, rd, og, sd = g.numpy(), reads.numpy(), origin.numpy(), strand.numpy()
+    comp = np.array([3, 2, 1, 0, 4], np.uint8)
+    bounds = np.cumsum(lens)
+    for r in range(0, 5000, 7):
+        w = gn[og[r]:og[r] + 60]
+        assert (w != 4).all()
+        assert np.searchsorted(bounds, og[r], side="right") == np.searchsorted(bounds, og[r] + 59, side="right")
+        if sd[r]:
+            w = comp[w[::-1]]
+        diff = (rd[r] != w) & (rd[r] != 4)
+        assert diff.sum() <= 2 and (rd[r] == 4).sum() <= 1
