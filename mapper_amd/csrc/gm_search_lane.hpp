@@ -95,14 +95,23 @@ __device__ __forceinline__ void lane_rank(const uint4 &s0, const uint4 &s1, cons
    const uint32_t m0 = (uint32_t)lo, m1 = (uint32_t)(lo >> 32), m2 = (uint32_t)hi, m3 = (uint32_t)(hi >> 32);
    uint32_t a = s0.w & CNT_MASK, c = s1.w & CNT_MASK, g = s2.w & CNT_MASK, tt = s3.w & CNT_MASK;
    uint32_t n = (s0.w >> 25) | ((s1.w >> 25) << 7) | ((s2.w >> 25) << 14) | ((s3.w >> 25) << 21);
+   // v_bitop3_b32: result bit = imm[(a << 2) | (b << 1) | c]; one instruction per symbol mask, one
+   // v_bcnt_u32_b32 (popcount + add) per count.  S.x, S.y, S.z = planes b0, b1, b2 of 32 positions.
 #define GM_SUB(S, M) { \
-      const uint32_t x = ~S.z & M; \
-      a += __popc(x & ~S.y & ~S.x); c += __popc(x & ~S.y & S.x); g += __popc(x & S.y & ~S.x); tt += __popc(x & S.y & S.x); \
-      n += __popc(S.z & ~S.x & M); }
+      const uint32_t x = __builtin_amdgcn_bitop3_b32(M, S.z, S.z, 0x10);            /* M & ~b2: A C G T */ \
+      a  += __popc(__builtin_amdgcn_bitop3_b32(x, S.y, S.x, 0x10));                 /* x & ~b1 & ~b0 */ \
+      c  += __popc(__builtin_amdgcn_bitop3_b32(x, S.y, S.x, 0x20));                 /* x & ~b1 &  b0 */ \
+      g  += __popc(__builtin_amdgcn_bitop3_b32(x, S.y, S.x, 0x40));                 /* x &  b1 & ~b0 */ \
+      tt += __popc(__builtin_amdgcn_bitop3_b32(x, S.y, S.x, 0x80));                 /* x &  b1 &  b0 */ \
+      n  += __popc(__builtin_amdgcn_bitop3_b32(S.z, S.x, M, 0x20)); }               /* b2 & ~b0 & M  */
    GM_SUB(s0, m0) GM_SUB(s1, m1) GM_SUB(s2, m2) GM_SUB(s3, m3)
 #undef GM_SUB
    rel[0] = a; rel[1] = c; rel[2] = g; rel[3] = tt; rel[4] = n;
 }
+
+// Keeps the compiler from carrying values derived from a block across the point where some lanes
+// replace the block (it would merge the two versions with a register move per derived value).
+__device__ __forceinline__ void pin(uint4 &v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
 
 constexpr int PH_LDS_ROWS = 8;       // phase-record rows (read lengths) kept in LDS; others are read from global memory
 
@@ -237,7 +246,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_search_lane(SearchArgs A)
       const uint32_t b0 = (uint32_t)(e0 >> BLOCK_POS_LOG), b1 = (uint32_t)(e1 >> BLOCK_POS_LOG);
       const unsigned long long need1m = __ballot(have && b1 != b0);
       uint4 f00, f01, f02, f03, f10, f11, f12, f13;
-      f00 = f01 = f02 = f03 = f10 = f11 = f12 = f13 = make_uint4(0, 0, 0, 0);
+      f00 = f01 = f02 = f03 = f10 = f11 = f12 = f13 = make_uint4(0, 0, 0, 0);   // (leaving these undefined costs 90 registers)
       quad_fetch<0>(occ, b0 << 6, havem, sub16, f00); quad_fetch<1>(occ, b0 << 6, havem, sub16, f01);
       quad_fetch<2>(occ, b0 << 6, havem, sub16, f02); quad_fetch<3>(occ, b0 << 6, havem, sub16, f03);
       if (need1m) {
@@ -256,13 +265,12 @@ __global__ void __launch_bounds__(WG_THREADS) k_search_lane(SearchArgs A)
       wave_sync();
       if (have) { g0 = stage_r[0]; g1 = stage_r[1]; g2 = stage_r[2]; g3 = stage_r[3]; }
       lane_rank(g0, g1, g2, g3, (int)(e0 & (BLOCK_POS - 1)), rel0);
-      if (need1m) {
-         wave_sync();
-         quad_stage<0>(stage_w, need1m, f10); quad_stage<1>(stage_w, need1m, f11);
-         quad_stage<2>(stage_w, need1m, f12); quad_stage<3>(stage_w, need1m, f13);
-         wave_sync();
-         if (have && b1 != b0) { g0 = stage_r[0]; g1 = stage_r[1]; g2 = stage_r[2]; g3 = stage_r[3]; }
-      }
+      wave_sync();
+      quad_stage<0>(stage_w, need1m, f10); quad_stage<1>(stage_w, need1m, f11);
+      quad_stage<2>(stage_w, need1m, f12); quad_stage<3>(stage_w, need1m, f13);
+      wave_sync();
+      if (have && b1 != b0) { g0 = stage_r[0]; g1 = stage_r[1]; g2 = stage_r[2]; g3 = stage_r[3]; }
+      pin(g0); pin(g1); pin(g2); pin(g3);
       lane_rank(g0, g1, g2, g3, (int)(e1 & (BLOCK_POS - 1)), rel1);
       wave_sync();
       const int qc = (int)((qword >> (8 * (pos & 3))) & 0xff);
