@@ -146,6 +146,12 @@ int gpumap_sar_get_range(gpumap_ctx *ctx, int64_t beg, int64_t size, int64_t *ve
 int gpumap_encode(gpumap_ctx *ctx, const char *text, const int64_t *offsets, int64_t n_reads,
                   uint8_t *codes);
 
+/* Page-locked host memory for read buffers handed to gpumap_batch_upload* (the copy to the GPU then
+** runs at the full rate of the link; pageable memory works too, slower).  No reference counterpart:
+** the reference never leaves the host. */
+void *gpumap_host_alloc(size_t bytes);
+void  gpumap_host_free(void *p);
+
 /* ------------------------------------------------------------------------------------------
 ** Read mapping: blocksearch_trail_rec(q, 0, m-1, tau+1, 0, bwt, tree) for every read, then
 ** sar_get_range for every hit, then the strand rule.
@@ -178,6 +184,10 @@ typedef struct {
    ** calls of the reference schedule) and device milliseconds of the stages. */
    int64_t   n_ext;
    float     ms_search, ms_locate, ms_sort, ms_total;
+   /* Not NULL: the arrays lie in the context's pinned result arena (option "pinned_results") and stay
+   ** valid until the next gpumap_batch_fetch / gpumap_map_batch on that context; gpumap_hits_free
+   ** then only clears the struct. */
+   void     *arena;
 } gpumap_hits;
 
 /* Host buffers in, host arrays out (malloc'ed by the library, released by gpumap_hits_free).

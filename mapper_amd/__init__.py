@@ -51,7 +51,7 @@ class _Hits(C.Structure):
         ("hit_rp", C.POINTER(C.c_int64)), ("hit_sz", C.POINTER(C.c_int64)), ("hit_dp", C.POINTER(C.c_int64)),
         ("hit_score", C.POINTER(C.c_int64)), ("hit_align", C.POINTER(C.c_uint64)),
         ("n_ext", C.c_int64), ("ms_search", C.c_float), ("ms_locate", C.c_float), ("ms_sort", C.c_float),
-        ("ms_total", C.c_float),
+        ("ms_total", C.c_float), ("arena", C.c_void_p),
     ]
 
 
@@ -85,6 +85,8 @@ API = {
     "gpumap_batch_free": (None, [_P]),
     "gpumap_mapper": (_I, [C.c_char_p, _P, _P, _I, C.c_char_p]),
     "gpumap_set_option": (_I, [_P, C.c_char_p, _I64]),
+    "gpumap_host_alloc": (_P, [C.c_size_t]),
+    "gpumap_host_free": (None, [_P]),
     "gpumap_build_device": (_P, [_P, _I, _P, _I64, _I, _I]),
     "gpumap_reference_sizes": (_I, [_P, C.POINTER(_I64)]),
     "gpumap_reference_fetch": (_I, [_P, _P, _P, _P, _P]),

@@ -72,11 +72,14 @@ struct gpumap_ctx {
    int64_t wil_cnt = 0;
    // launch shape
    int cu_count = 256;
-   int waves_per_cu = 0;              // 0 = the variant's default
-   int variant = 1;                   // 0 = k_search (node per quad), 1 = k_search_lane (node per lane)
+   int waves_per_cu = 0;              // 0 = default (12)
    int64_t spill_cap = 16384;         // nodes per wave
    // scratch kept across runs
    DevBuf spill, counters, op_in, op_out, cub_tmp;
+   // option "pinned_results": results are fetched into one page-locked arena owned by the context
+   bool pinned_results = false;
+   void *pin_arena = nullptr;
+   size_t pin_cap = 0;
 };
 
 

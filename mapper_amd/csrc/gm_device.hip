@@ -9,7 +9,7 @@
 #include <vector>
 #include "gm_devctx.hpp"
 #include "gm_kernels.hpp"
-#include "gm_search_lane.hpp"
+#include "gm_search.hpp"
 
 using namespace gm;
 
@@ -55,7 +55,6 @@ int gm_ctx_common_init(gpumap_ctx *ctx, int device)
    HIP_TRY(hipMalloc((void **)&ctx->d_sym_table, 256));
    HIP_TRY(hipMemcpy(ctx->d_sym_table, ctx->sym_table, 256, hipMemcpyHostToDevice));
    HIP_TRY(ctx->counters.ensure(64));
-   if (const char *e = getenv("GPUMAP_SEARCH_VARIANT")) ctx->variant = atoi(e) == 0 ? 0 : 1;   // tuning aid
    return 0;
 failure_return:
    return -1;
@@ -75,6 +74,7 @@ extern "C" void gpumap_destroy(gpumap_ctx *ctx)
    if (ctx->d_text) (void)hipFree(ctx->d_text);
    if (ctx->d_sym_table) (void)hipFree(ctx->d_sym_table);
    for (DevBuf *b : {&ctx->spill, &ctx->counters, &ctx->op_in, &ctx->op_out, &ctx->cub_tmp}) b->release();
+   if (ctx->pin_arena) (void)hipHostFree(ctx->pin_arena);
    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
    delete ctx;
 }
@@ -245,7 +245,7 @@ extern "C" int gpumap_set_option(gpumap_ctx *ctx, const char *name, int64_t valu
 {
    GM_FAIL_IF(ctx == nullptr || name == nullptr, "NULL argument.");
    if (!strcmp(name, "waves_per_cu")) { GM_FAIL_IF(value < 0 || value > 32, "waves_per_cu out of range."); ctx->waves_per_cu = (int)value; }
-   else if (!strcmp(name, "search_variant")) { GM_FAIL_IF(value < 0 || value > 1, "search_variant out of range."); ctx->variant = (int)value; }
+   else if (!strcmp(name, "pinned_results")) ctx->pinned_results = value != 0;
    else if (!strcmp(name, "spill_nodes")) { GM_FAIL_IF(value < 0 || value > (1 << 22), "spill_nodes out of range."); ctx->spill_cap = value ? ((value + SPILL_CHUNK - 1) / SPILL_CHUNK) * SPILL_CHUNK : 16384; }
    else GM_FAIL("unknown option.");
    return 0;
@@ -502,10 +502,7 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
          A.cursor = cnt + 0; A.hits = b->hits.as<Node>(); A.hit_cap = hit_cap; A.hit_count = cnt + 1; A.n_ext = cnt + 2;
          A.spill = ctx->spill.as<Node>(); A.spill_cap = (uint32_t)ctx->spill_cap; A.error = (int *)(cnt + 3); A.stats = cnt + 4;
          if (R > 0) {
-            if (ctx->variant == 1)
-               hipLaunchKernelGGL(k_search_lane, dim3((unsigned)n_wg), dim3(WG_THREADS), (size_t)ctx->ix.n_super * SYMS * 8, st, A);
-            else
-               hipLaunchKernelGGL(k_search, dim3((unsigned)n_wg), dim3(WG_THREADS), 0, st, A);
+            hipLaunchKernelGGL(k_search, dim3((unsigned)n_wg), dim3(WG_THREADS), (size_t)ctx->ix.n_super * SYMS * 8, st, A);
             HIP_TRY(hipGetLastError());
          }
          HIP_TRY(hipMemcpyAsync(host_cnt, cnt, 64, hipMemcpyDeviceToHost, st));
@@ -633,23 +630,53 @@ failure_return:
    return -1;
 }
 
+extern "C" void *gpumap_host_alloc(size_t bytes)
+{
+   void *p = nullptr;
+   if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+      GM_WARN("cannot allocate page-locked host memory.");
+      errno = 1;
+      return nullptr;
+   }
+   return p;
+}
+
+extern "C" void gpumap_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
 extern "C" void gpumap_hits_free(gpumap_hits *h)
 {
    if (!h) return;
-   free(h->status); free(h->read_first_loc); free(h->loc_read); free(h->loc_pos); free(h->loc_fwd); free(h->loc_seq);
-   free(h->loc_seqpos); free(h->loc_strand); free(h->loc_score);
-   free(h->hit_read); free(h->hit_fp); free(h->hit_rp); free(h->hit_sz); free(h->hit_dp); free(h->hit_score); free(h->hit_align);
+   if (!h->arena) {
+      free(h->status); free(h->read_first_loc); free(h->loc_read); free(h->loc_pos); free(h->loc_fwd); free(h->loc_seq);
+      free(h->loc_seqpos); free(h->loc_strand); free(h->loc_score);
+      free(h->hit_read); free(h->hit_fp); free(h->hit_rp); free(h->hit_sz); free(h->hit_dp); free(h->hit_score); free(h->hit_align);
+   }
    memset(h, 0, sizeof *h);
 }
 
+namespace {
+// Destination of one fetch: malloc'ed arrays, or slices of the context's page-locked arena.
+struct FetchDst {
+   char *arena = nullptr;
+   size_t used = 0;
+   template <class T> T *take(int64_t count)
+   {
+      size_t bytes = sizeof(T) * (size_t)std::max<int64_t>(count, 1);
+      if (!arena) return (T *)malloc(bytes);
+      T *p = (T *)(arena + used);
+      used += (bytes + 255) & ~(size_t)255;
+      return p;
+   }
+};
 template <class T>
-static int fetch_array(T **dst, const DevBuf &src, int64_t count, hipStream_t st)
+int fetch_array(FetchDst &d, T **dst, const DevBuf &src, int64_t count, hipStream_t st)
 {
-   *dst = (T *)malloc(sizeof(T) * (size_t)std::max<int64_t>(count, 1));
+   *dst = d.take<T>(count);
    if (!*dst) return -1;
    if (count > 0 && hipMemcpyAsync(*dst, src.p, sizeof(T) * (size_t)count, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
    return 0;
 }
+}  // namespace
 
 extern "C" int gpumap_batch_fetch(gpumap_ctx *ctx, gpumap_batch *b, gpumap_hits *out)
 {
@@ -660,26 +687,38 @@ extern "C" int gpumap_batch_fetch(gpumap_ctx *ctx, gpumap_batch *b, gpumap_hits 
    {
       hipStream_t st = ctx->stream;
       const int64_t R = b->n_reads, L = b->n_locs, H = b->have_intervals ? b->n_hits : 0;
+      FetchDst d;
+      if (ctx->pinned_results) {
+         size_t need = 16 * 256 + 8 * (size_t)(2 * R + 1) + 42 * (size_t)L + 80 * (size_t)H;
+         if (need > ctx->pin_cap) {
+            if (ctx->pin_arena) { HIP_TRY(hipHostFree(ctx->pin_arena)); ctx->pin_arena = nullptr; ctx->pin_cap = 0; }
+            need += need / 4;
+            HIP_TRY(hipHostMalloc(&ctx->pin_arena, need, hipHostMallocDefault));
+            ctx->pin_cap = need;
+         }
+         d.arena = (char *)ctx->pin_arena;
+         out->arena = ctx->pin_arena;
+      }
       out->n_reads = R; out->n_locs = L; out->n_hits = H; out->n_ext = b->n_ext;
       out->ms_search = b->ms[0]; out->ms_locate = b->ms[1]; out->ms_sort = b->ms[2]; out->ms_total = b->ms[3];
       int rc = 0;
-      rc |= fetch_array(&out->status, b->status, R, st);
-      rc |= fetch_array(&out->read_first_loc, b->read_first, R + 1, st);
-      rc |= fetch_array(&out->loc_read, b->loc_read, L, st);
-      rc |= fetch_array(&out->loc_pos, b->loc_pos, L, st);
-      rc |= fetch_array(&out->loc_fwd, b->loc_fwd, L, st);
-      rc |= fetch_array(&out->loc_seq, b->loc_seq, L, st);
-      rc |= fetch_array(&out->loc_seqpos, b->loc_seqpos, L, st);
-      rc |= fetch_array(&out->loc_strand, b->loc_strand, L, st);
-      rc |= fetch_array(&out->loc_score, b->loc_score, L, st);
+      rc |= fetch_array(d, &out->status, b->status, R, st);
+      rc |= fetch_array(d, &out->read_first_loc, b->read_first, R + 1, st);
+      rc |= fetch_array(d, &out->loc_read, b->loc_read, L, st);
+      rc |= fetch_array(d, &out->loc_pos, b->loc_pos, L, st);
+      rc |= fetch_array(d, &out->loc_fwd, b->loc_fwd, L, st);
+      rc |= fetch_array(d, &out->loc_seq, b->loc_seq, L, st);
+      rc |= fetch_array(d, &out->loc_seqpos, b->loc_seqpos, L, st);
+      rc |= fetch_array(d, &out->loc_strand, b->loc_strand, L, st);
+      rc |= fetch_array(d, &out->loc_score, b->loc_score, L, st);
       if (b->have_intervals) {
-         rc |= fetch_array(&out->hit_read, b->hit_read, H, st);
-         rc |= fetch_array(&out->hit_fp, b->hit_fp, H, st);
-         rc |= fetch_array(&out->hit_rp, b->hit_rp, H, st);
-         rc |= fetch_array(&out->hit_sz, b->hit_sz, H, st);
-         rc |= fetch_array(&out->hit_dp, b->hit_dp, H, st);
-         rc |= fetch_array(&out->hit_score, b->hit_score, H, st);
-         rc |= fetch_array(&out->hit_align, b->hit_align, 4 * H, st);
+         rc |= fetch_array(d, &out->hit_read, b->hit_read, H, st);
+         rc |= fetch_array(d, &out->hit_fp, b->hit_fp, H, st);
+         rc |= fetch_array(d, &out->hit_rp, b->hit_rp, H, st);
+         rc |= fetch_array(d, &out->hit_sz, b->hit_sz, H, st);
+         rc |= fetch_array(d, &out->hit_dp, b->hit_dp, H, st);
+         rc |= fetch_array(d, &out->hit_score, b->hit_score, H, st);
+         rc |= fetch_array(d, &out->hit_align, b->hit_align, 4 * H, st);
       }
       HIP_TRY(hipStreamSynchronize(st));
       GM_FAIL_IF(rc != 0, "memory error.");
@@ -722,6 +761,7 @@ extern "C" int gpumap_mapper(const char *qfile, const gpumap_index *index, gpuma
    GM_FAIL_IF(ctx == nullptr, "argument 'ctx' is NULL.");
    in = gm_reads_open(qfile);
    GM_FAIL_IF(in == nullptr, "cannot open the read file.");
+   ctx->pinned_results = true;          // h is consumed before the next fetch
    fo = (out_path == nullptr || !strcmp(out_path, "-")) ? stdout : fopen(out_path, "w");
    GM_FAIL_IF(fo == nullptr, "cannot open the output file.");
    {

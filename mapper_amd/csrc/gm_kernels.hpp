@@ -6,17 +6,9 @@
 //   k_encode                        K4  letters -> codes, fixed-stride read matrix
 //   k_occ_all, k_query_all, k_sar_get   batched forms of the reference's single-query operators
 //
-// Design notes (DESIGN.md has the long form):
-//  * The path is integer and gather-bound: no MFMA.  What is tuned is the number of cache lines
-//    touched per extension step and the number of independent chains in flight.
-//  * Four neighbouring lanes ("quad") own one search node.  A rank query is one 16-byte load per
-//    lane (one 64-byte line per quad, fully used), a popcount over 32 positions per lane and two
-//    DPP quad_perm adds.  In branching steps lane k of the quad evaluates the child for symbol k.
-//  * The recursion of the reference (seqsearch_* calling itself, the pathstack_t per tree level)
-//    becomes a per-wavefront deque of 32-byte nodes in LDS: pushes are compacted with
-//    __ballot + popcount prefix, pops hand the newest nodes to idle quads (LIFO keeps the
-//    frontier small); the oldest part of the deque spills to a per-wave global buffer when full.
-//  * Exact continuation (the "dash", most steps) keeps its node in registers: no LDS traffic.
+// Design notes (DESIGN.md has the long form): the path is integer and gather-bound, no MFMA.  What is
+// tuned is the number of cache lines touched per extension step, the number of independent chains
+// in flight and the number of instructions per step.  The search kernel is in gm_search.hpp.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "gm_core.hpp"
@@ -26,8 +18,8 @@ namespace gm {
 
 constexpr int WG_WAVES = 4;
 constexpr int WG_THREADS = 64 * WG_WAVES;
-constexpr int QCAP = 256;            // deque capacity per wave (nodes), power of two
-constexpr int SPILL_CHUNK = 128;     // nodes moved per spill / reload
+constexpr int QCAP = 128;            // deque capacity per wave (nodes), power of two
+constexpr int SPILL_CHUNK = 64;      // nodes moved per spill / reload
 
 // ------------------------------------------------------------------------------------------------
 // K0: repack
@@ -209,13 +201,6 @@ struct SearchArgs {
    unsigned long long *stats;   // [0] passes of the main loop over all waves, [1] continuations pushed
 };
 
-__device__ __forceinline__ uint32_t quad_sum(uint32_t x)
-{
-   x += (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
-   x += (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
-   return x;
-}
-
 // Selection by a per-lane index, written over values (not over the array) so that the arrays stay
 // in registers: a select chain over array elements is turned into an indexed stack access.
 template <class T>
@@ -287,213 +272,7 @@ __device__ __forceinline__ void wave_push(WaveQueue &wq, bool flag, const Node &
    wq.top += (uint32_t)__popcll(m);
 }
 
-// Converged call: lanes with `flag` append `nd` to the global hit list.
-__device__ __forceinline__ void wave_emit(const SearchArgs &A, bool flag, const Node &nd, int lane)
-{
-   unsigned long long m = __ballot(flag);
-   if (m == 0) return;
-   unsigned long long base = 0;
-   int leader = __ffsll((long long)m) - 1;
-   if (lane == leader) base = atomicAdd(A.hit_count, (unsigned long long)__popcll(m));
-   base = __shfl(base, leader);
-   if (flag) {
-      unsigned long long at = base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
-      if (at < A.hit_cap) {
-         uint4 *d = reinterpret_cast<uint4 *>(A.hits + at);
-         d[0] = make_uint4(nd.w[0], nd.w[1], nd.w[2], nd.w[3]);
-         d[1] = make_uint4(nd.w[4], nd.w[5], nd.w[6], nd.w[7]);
-      }
-   }
-}
-
-__global__ void __launch_bounds__(WG_THREADS) k_search(SearchArgs A)
-{
-   __shared__ Node s_q[WG_WAVES][QCAP];
-   __shared__ unsigned long long s_cb[MAX_SB_LDS * SYMS];    // C[j] + count of j before superblock s
-
-   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, sub = lane & 3;
-   const uint32_t gw = blockIdx.x * WG_WAVES + wid;
-   for (int i = tid; i < (int)A.ix.n_super * SYMS; i += WG_THREADS)
-      s_cb[i] = A.ix.tables[TAB_SBASE + i] + A.ix.tables[TAB_C + i % SYMS];
-   __syncthreads();
-
-   WaveQueue wq;
-   wq.q = s_q[wid];
-   wq.spill = A.spill + (size_t)gw * A.spill_cap;
-   wq.bot = wq.top = wq.spill_top = 0;
-   wq.spill_cap = A.spill_cap;
-   wq.error = A.error;
-
-   const int seeds_per = A.tau + 1;
-   const int reads_per_refill = 64 / seeds_per;
-   const unsigned long long lt_mask = (1ull << lane) - 1ull;
-   const uint4 *occ4 = reinterpret_cast<const uint4 *>(A.ix.occ);
-
-   bool reads_left = true;
-   bool have = false;
-   NodeR cur;
-   cur.fp = cur.rp = cur.sz = 0; cur.read = 0; cur.mm = 0;
-   cur.pos = cur.end = cur.phase = cur.score = cur.sref = cur.tau = cur.diff = 0;
-   cur.dash = cur.fw = false;
-   unsigned long long ext_count = 0;
-
-   for (;;) {
-      // ------------------------------------------------------------ hand nodes to idle quads
-      unsigned long long needm = __ballot(!have && sub == 0);
-      int nneed = __popcll(needm);
-      if (nneed) {
-         int count = (int)(wq.top - wq.bot);
-         if (count < nneed) {
-            if (wq.spill_top > 0) {
-               wq.spill_top -= SPILL_CHUNK;
-               for (int i = lane; i < SPILL_CHUNK; i += 64) {
-                  const uint4 *s = reinterpret_cast<const uint4 *>(wq.spill + wq.spill_top + i);
-                  uint4 a = s[0], b = s[1];
-                  Node t;
-                  t.w[0] = a.x; t.w[1] = a.y; t.w[2] = a.z; t.w[3] = a.w;
-                  t.w[4] = b.x; t.w[5] = b.y; t.w[6] = b.z; t.w[7] = b.w;
-                  lds_store_node(wq.q, wq.top + i, t);
-               }
-               wq.top += SPILL_CHUNK;
-            } else if (reads_left) {
-               // Admit reads: one seed per leaf block of the schedule (src/blocksearch.c:138-144).
-               unsigned long long base = 0;
-               if (lane == 0) base = atomicAdd(A.cursor, (unsigned long long)reads_per_refill);
-               base = __shfl(base, 0);
-               if (base >= (unsigned long long)A.n_reads) {
-                  reads_left = false;
-               } else {
-                  int got = (int)min((unsigned long long)reads_per_refill, (unsigned long long)A.n_reads - base);
-                  int r = lane / seeds_per, leaf = lane - r * seeds_per;
-                  bool mk = r < got;
-                  Node packed;
-                  for (int k = 0; k < 8; k++) packed.w[k] = 0;
-                  if (mk) {
-                     uint32_t read = (uint32_t)(base + r);
-                     int m = A.read_len[read];
-                     int row = m <= MAX_READ ? A.len_row[m] : 0xff;
-                     mk = row != 0xff;
-                     if (mk) {
-                        NodeR sd;
-                        sd.fp = 0; sd.rp = 0; sd.sz = A.ix.n;        // bwt_new_query, src/index_bwt.c:48-52
-                        sd.read = read; sd.score = 0; sd.mm = (uint64_t)row << 56;
-                        sd.sref = 0; sd.pos = sd.end = sd.tau = sd.diff = sd.phase = 0; sd.dash = sd.fw = false;
-                        enter_phase(sd, leaf, A.phases[row * MAX_PHASES + leaf]);
-                        pack_node(sd, packed);
-                     }
-                  }
-                  wave_push(wq, mk, packed, lane);
-               }
-            }
-            wave_sync();
-            count = (int)(wq.top - wq.bot);
-         }
-         if (!have) {
-            int rank = __popcll(needm & ((1ull << (lane & ~3)) - 1ull));
-            if (rank < count) {
-               Node nd;
-               lds_load_node(wq.q, wq.top - 1 - (uint32_t)rank, nd);
-               unpack_node(nd, cur);
-               have = true;
-            }
-         }
-         wq.top -= (uint32_t)min(nneed, count);
-         wave_sync();
-      }
-      if (!__any(have)) {
-         if (!reads_left && wq.spill_top == 0 && wq.top == wq.bot) break;
-         continue;
-      }
-      ext_count += (unsigned long long)__popcll(__ballot(have && sub == 0));
-
-      // ------------------------------------------------------------ one extension step per quad
-      bool push1 = false, emit1 = false, push2 = false, emit2 = false, branching = false;
-      Node out1, out2;
-      for (int k = 0; k < 8; k++) { out1.w[k] = 0; out2.w[k] = 0; }
-      if (have) {
-         const int64_t a = cur.fw ? cur.rp : cur.fp, other = cur.fw ? cur.fp : cur.rp;
-         const int64_t e0 = a, e1 = a + cur.sz;                       // ranks at a-1 and a+sz-1, exclusive form
-         const int64_t b0 = e0 >> BLOCK_POS_LOG, b1 = e1 >> BLOCK_POS_LOG;
-         uint4 v0 = occ4[b0 * 4 + sub];
-         uint4 v1 = v0;
-         if (b1 != b0) v1 = occ4[b1 * 4 + sub];
-         const int qc = A.reads[(size_t)cur.read * A.stride + cur.pos];
-         const int row = (int)(cur.mm >> 56);
-
-         int t0 = (int)(e0 & (BLOCK_POS - 1)) - 32 * sub; t0 = t0 < 0 ? 0 : (t0 > 32 ? 32 : t0);
-         int t1 = (int)(e1 & (BLOCK_POS - 1)) - 32 * sub; t1 = t1 < 0 ? 0 : (t1 > 32 ? 32 : t1);
-         uint32_t c0[SYMS], c1[SYMS];
-         sub_counts(v0.x, v0.y, v0.z, t0, c0);
-         sub_counts(v1.x, v1.y, v1.z, t1, c1);
-         // running counts: lane k carries symbol k's 25-bit count and 7 bits of N's
-         uint32_t own0 = v0.w & CNT_MASK, own1 = v1.w & CNT_MASK;
-         c0[0] += sub == 0 ? own0 : 0; c0[1] += sub == 1 ? own0 : 0; c0[2] += sub == 2 ? own0 : 0; c0[3] += sub == 3 ? own0 : 0;
-         c1[0] += sub == 0 ? own1 : 0; c1[1] += sub == 1 ? own1 : 0; c1[2] += sub == 2 ? own1 : 0; c1[3] += sub == 3 ? own1 : 0;
-         c0[4] += (v0.w >> 25) << (7 * sub);
-         c1[4] += (v1.w >> 25) << (7 * sub);
-         for (int j = 0; j < SYMS; j++) { c0[j] = quad_sum(c0[j]); c1[j] = quad_sum(c1[j]); }
-
-         const int sb0 = (int)(e0 >> SUPER_LOG), sb1 = (int)(e1 >> SUPER_LOG);
-         int64_t szn[SYMS], rpn[SYMS];
-         for (int j = 0; j < SYMS; j++) szn[j] = (int64_t)c1[j] - (int64_t)c0[j];
-         if (sb1 != sb0)
-            for (int j = 0; j < SYMS; j++) szn[j] += (int64_t)(s_cb[sb1 * SYMS + j] - s_cb[sb0 * SYMS + j]);
-         // bwt_query_all, src/index_bwt.c:262-273
-         int64_t tot = szn[0] + szn[1] + szn[2] + szn[3] + szn[4];
-         rpn[3] = other + (cur.sz - tot);
-         rpn[2] = rpn[3] + szn[3];
-         rpn[1] = rpn[2] + szn[2];
-         rpn[0] = rpn[1] + szn[1];
-         rpn[4] = rpn[0] + szn[0];
-
-         const bool sticky = cur.dash && qc != UNKNOWN;
-         branching = !sticky;
-         {
-            const int nt = sticky ? qc : sub;
-            const int js = cur.fw ? complement(nt) : nt;
-            const int64_t fpn = (int64_t)(s_cb[sb0 * SYMS + js] + sel5(c0, js));
-            const int64_t rp_ = sel5(rpn, js), sz_ = sel5(szn, js);
-            NodeR child;
-            int kind = make_child(cur, nt, qc, cur.fw ? rp_ : fpn, cur.fw ? fpn : rp_, sz_, child);
-            bool done_final = false;
-            if (kind == CHILD_DONE) {
-               int nxt = phase_next(A.phases[row * MAX_PHASES + cur.phase]);
-               if (nxt == PHASE_FINAL) done_final = true;
-               else { enter_phase(child, nxt, A.phases[row * MAX_PHASES + nxt]); kind = CHILD_NODE; }
-            }
-            if (sticky) {
-               if (done_final) { emit1 = sub == 0; child.pos = 0; pack_node(child, out1); have = false; }
-               else if (kind == CHILD_NODE) cur = child;
-               else have = false;
-            } else {
-               if (done_final) { emit1 = true; child.pos = 0; pack_node(child, out1); }
-               else if (kind == CHILD_NODE) { push1 = true; pack_node(child, out1); }
-            }
-         }
-         // text N as a branch (nt = 4): explored like any other symbol (src/blocksearch.c:207)
-         if (branching && sub == 0 && szn[4] >= 1) {
-            const int64_t fpn = (int64_t)(s_cb[sb0 * SYMS + 4] + c0[4]);
-            NodeR child;
-            int kind = make_child(cur, 4, qc, cur.fw ? rpn[4] : fpn, cur.fw ? fpn : rpn[4], szn[4], child);
-            if (kind == CHILD_DONE) {
-               int nxt = phase_next(A.phases[row * MAX_PHASES + cur.phase]);
-               if (nxt == PHASE_FINAL) { emit2 = true; child.pos = 0; pack_node(child, out2); kind = CHILD_NONE; }
-               else { enter_phase(child, nxt, A.phases[row * MAX_PHASES + nxt]); kind = CHILD_NODE; }
-            }
-            if (kind == CHILD_NODE) { push2 = true; pack_node(child, out2); }
-         }
-         if (branching) have = false;
-      }
-      // ------------------------------------------------------------ converged: queue and hit traffic
-      if (__any(push1)) { wave_push(wq, push1, out1, lane); }
-      if (__any(push2)) { wave_push(wq, push2, out2, lane); }
-      wave_emit(A, emit1, out1, lane);
-      wave_emit(A, emit2, out2, lane);
-      wave_sync();
-      (void)lt_mask;
-   }
-   if (lane == 0 && ext_count) atomicAdd(A.n_ext, ext_count);
-}
+// (k_search itself is in gm_search.hpp.)
 
 // ------------------------------------------------------------------------------------------------
 // K3: locate.  hit_off = exclusive scan of the hit sizes.  Output slot t belongs to the hit h with

@@ -1,31 +1,39 @@
-// gm_search_lane.hpp -- k_search_lane: the block search with one search node per lane.
+// gm_search.hpp -- k_search: the block search of a batch of reads, one search node per lane.
 //
-// Same schedule, node format, queue and output as k_search (gm_kernels.hpp); what differs is the
-// mapping of nodes to lanes.  k_search gives a node to a quad of lanes, so a wave advances 16 nodes
-// per pass of the loop and is bound by instruction issue (about 750 vector instructions per pass,
-// profiles/r1_*).  Here a wave advances 64 nodes per pass:
+// Replaces blocksearch_trail_rec + seqsearch_fw/bw + seqdash_fw/bw (src/blocksearch.c:106-496) with
+// bwt_query_all / get_occ_all (src/index_bwt.c:198-304, :840-905) inlined.
 //
-//  * fetch: the 64-byte Occ block of a node is still read by its quad, one 16-byte load per lane
-//    (four load instructions per rank, each touching 16 lines per wave).  A lane reading its own
+//  * A node = one pending call of seqsearch_* / one iteration of seqdash_*: bi-interval, next query
+//    position, packed phase bookkeeping (gm_core.hpp).  A wave advances 64 nodes per pass of its loop.
+//  * fetch: the 64-byte Occ block of a node is read by the node's quad of lanes, one 16-byte load per
+//    lane (four load instructions per rank, each touching 16 lines per wave).  A lane reading its own
 //    line with four loads runs 3x slower on footprints of several GiB
 //    (profiles/r1_gather_microbench.jsonl, shape lane64 against quad64).
 //  * hand-over: the four sub-blocks reach the owning lane through a per-wave LDS staging area
 //    (80-byte slots: conflict-free 16-byte writes and reads).
-//  * rank, bwt_query_all and the child rules run per lane; the first child stays in the lane's
-//    registers, further children go to the wave's LDS deque.
+//  * rank, bwt_query_all and the child rules run per lane.  A pass follows ONE child per node: the
+//    first valid candidate stays in the lane's registers; if more remain, the node itself goes back to
+//    the wave's LDS deque as a continuation (meta.first = next candidate) and is re-extended when
+//    popped.  Siblings are rare (repeats, query N); a loop over children would cost every lane of the
+//    wave a pass per sibling of any lane.
+//  * The recursion of the reference (seqsearch_* calling itself, pathstack_t per tree level) is that
+//    deque: pushes compacted with __ballot + popcount prefix, pops hand the newest nodes to idle lanes
+//    (LIFO keeps the frontier small); its oldest part spills to a per-wave global region when full.
+//  * Finished nodes are staged in a per-wave LDS ring; phase records (what a node becomes at the end
+//    of a phase) and the superblock counts sit in LDS.
+//  * History of the design (a node per quad of lanes, a loop over children, one atomic per emitting
+//    pass: 13 G extension steps/s; this kernel: 44-65 G) is in DESIGN.md section 3.
 #pragma once
 #include "gm_kernels.hpp"
 
 namespace gm {
 
-constexpr int LQCAP = 128;           // deque capacity per wave (nodes), power of two
-constexpr int LCHUNK = 64;           // nodes moved per spill / reload
 constexpr int STAGE_SLOT_U4 = 5;     // staging slot per lane, in 16-byte units (4 used + 1 pad)
 constexpr int HITBUF = 64;           // finished nodes staged per wave before they go to the global list
 
 // Finished nodes are staged in a per-wave LDS ring and leave it when the next ones would not fit: one
-// atomic on the global counter and one contiguous store of up to 2 KB per flush.  (One atomic per emitting pass, as in
-// k_search, serialises all waves on one address: about 10 ns per atomic, the whole kernel time.)
+// atomic on the global counter and one contiguous store of up to 2 KB per flush.  (One atomic per emitting
+// pass serialises all waves on one address: about 10 ns per atomic, which was the whole kernel time.)
 struct HitRing {
    Node *ring;
    uint32_t head, tail;
@@ -115,9 +123,9 @@ __device__ __forceinline__ void pin(uint4 &v) { asm volatile("" : "+v"(v.x), "+v
 
 constexpr int PH_LDS_ROWS = 8;       // phase-record rows (read lengths) kept in LDS; others are read from global memory
 
-__global__ void __launch_bounds__(WG_THREADS) k_search_lane(SearchArgs A)
+__global__ void __launch_bounds__(WG_THREADS) k_search(SearchArgs A)
 {
-   __shared__ Node s_q[WG_WAVES][LQCAP];
+   __shared__ Node s_q[WG_WAVES][QCAP];
    __shared__ uint4 s_stage[WG_WAVES][64 * STAGE_SLOT_U4];
    __shared__ Node s_hit[WG_WAVES][HITBUF];
    __shared__ uint2 s_ph[PH_LDS_ROWS * MAX_PHASES];
@@ -169,16 +177,16 @@ __global__ void __launch_bounds__(WG_THREADS) k_search_lane(SearchArgs A)
          int count = (int)(wq.top - wq.bot);
          if (count < nneed) {
             if (wq.spill_top > 0) {
-               wq.spill_top -= LCHUNK;
-               for (int i = lane; i < LCHUNK; i += 64) {
+               wq.spill_top -= SPILL_CHUNK;
+               for (int i = lane; i < SPILL_CHUNK; i += 64) {
                   const uint4 *sp = reinterpret_cast<const uint4 *>(wq.spill + wq.spill_top + i);
                   uint4 x = sp[0], y = sp[1];
                   Node t;
                   t.w[0] = x.x; t.w[1] = x.y; t.w[2] = x.z; t.w[3] = x.w;
                   t.w[4] = y.x; t.w[5] = y.y; t.w[6] = y.z; t.w[7] = y.w;
-                  lds_store_node<LQCAP>(wq.q, wq.top + i, t);
+                  lds_store_node<QCAP>(wq.q, wq.top + i, t);
                }
-               wq.top += LCHUNK;
+               wq.top += SPILL_CHUNK;
             } else if (reads_left) {
                // Admit reads: one seed per leaf block of the schedule (src/blocksearch.c:138-144).
                unsigned long long base = 0;
@@ -206,7 +214,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_search_lane(SearchArgs A)
                         pack_node(sd, packed);
                      }
                   }
-                  wave_push<LQCAP, LCHUNK>(wq, mk, packed, lane);
+                  wave_push<QCAP, SPILL_CHUNK>(wq, mk, packed, lane);
                }
             }
             wave_sync();
@@ -216,7 +224,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_search_lane(SearchArgs A)
             int rank = __popcll(needm & lt_mask);
             if (rank < count) {
                Node nd;
-               lds_load_node<LQCAP>(wq.q, wq.top - 1 - (uint32_t)rank, nd);
+               lds_load_node<QCAP>(wq.q, wq.top - 1 - (uint32_t)rank, nd);
                fp = (int64_t)nd.w[0] | ((int64_t)(nd.w[3] & 0xff) << 32);
                rp = (int64_t)nd.w[1] | ((int64_t)((nd.w[3] >> 8) & 0xff) << 32);
                sz = (int64_t)nd.w[2] | ((int64_t)((nd.w[3] >> 16) & 0xff) << 32);
@@ -301,7 +309,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_search_lane(SearchArgs A)
          const uint32_t rest = cand & (cand - 1);
          out.w[5] = (meta & ~(7u << META_FIRST)) | ((uint32_t)(__ffs((int)rest) - 1) << META_FIRST);
          out.w[6] = (uint32_t)mm; out.w[7] = (uint32_t)(mm >> 32);
-         wave_push<LQCAP, LCHUNK>(wq, cont, out, lane);
+         wave_push<QCAP, SPILL_CHUNK>(wq, cont, out, lane);
          n_cont += (unsigned long long)__popcll(__ballot(cont));
       }
       bool emit = false;
