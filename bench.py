@@ -12,6 +12,7 @@ batch is fixed, value = reads of all ranks / max-over-ranks time).
 
 A "step" is one pass of the hot path over one batch of reads already resident in HBM:
 gpumap_batch_run = search (k_search) + suffix-array locate + ordering, results left on the device.
+Default workload: the GRCh38-size index of config 4 (synthetic, generated and indexed in HBM).
 
 One JSON line is printed by rank 0; see DESIGN.md section "Measurement" for the accounting of
 `roofline` (algorithmic bytes = 128 B per extension step of the reference schedule, i.e. two
