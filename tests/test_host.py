@@ -153,6 +153,8 @@ def emu():
     E.emu_create.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
     E.emu_search.restype = C.c_int64
     E.emu_search.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.POINTER(C.c_int64))]
+    E.emu_search_packed.restype = C.c_int64
+    E.emu_search_packed.argtypes = E.emu_search.argtypes
     E.emu_occ_all.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
     E.emu_free.argtypes = [C.c_void_p]
     E.emu_destroy.argtypes = [C.c_void_p]
@@ -161,7 +163,9 @@ def emu():
 
 def test_kernel_core_block_layout_and_schedule_on_host(emu, workdir):
     """gm_core.hpp (rank blocks, node packing, phase table, per-node step), run sequentially on the
-    host, gives the oracle's ranks, hits and extension-step counts."""
+    host, gives the oracle's ranks, hits and extension-step counts: both in the plain form
+    (make_child over all five symbols) and in the form k_search runs (one child per pass chosen by
+    valid_children / child_meta, continuations, phase records)."""
     base = common.build_golden_index(workdir, "small")
     hix = ma.HostIndex.read(base)
     v = hix.view
@@ -181,18 +185,20 @@ def test_kernel_core_block_layout_and_schedule_on_host(emu, workdir):
             hp = C.POINTER(po.OrcHit)()
             ne = C.c_int64()
             nref = po.lib().orc_blocksearch(orc._h, q.ctypes.data_as(C.POINTER(C.c_uint8)), len(q), tau, C.byref(hp), C.byref(ne))
-            op = C.POINTER(C.c_int64)()
-            n = emu.emu_search(h, q.ctypes.data_as(C.c_void_p), len(q), tau, C.byref(op))
-            if nref < 0:
-                assert n == -1
-                continue
-            mine = sorted(tuple(int(op[10 * i + k]) for k in range(9)) for i in range(n))
             want = sorted((x.fp, x.rp, x.sz, x.dp, x.score) + tuple(int(np.int64(np.uint64(a))) for a in x.align)
-                          for x in (hp[i] for i in range(nref)))
-            assert mine == want
-            assert (int(op[9]) if n > 0 else int(op[0])) == ne.value
-            emu.emu_free(op)
-            po.lib()._libc.free(C.cast(hp, C.c_void_p))
+                          for x in (hp[i] for i in range(max(nref, 0))))
+            for search in (emu.emu_search, emu.emu_search_packed):
+                op = C.POINTER(C.c_int64)()
+                n = search(h, q.ctypes.data_as(C.c_void_p), len(q), tau, C.byref(op))
+                if nref < 0:
+                    assert n == -1
+                    continue
+                mine = sorted(tuple(int(op[10 * i + k]) for k in range(9)) for i in range(n))
+                assert mine == want
+                assert (int(op[9]) if n > 0 else int(op[0])) == ne.value
+                emu.emu_free(op)
+            if nref >= 0:
+                po.lib()._libc.free(C.cast(hp, C.c_void_p))
     emu.emu_destroy(h)
 
 
