@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--waves-per-cu", type=int, default=0)
     ap.add_argument("--device-build", action="store_true", help="generate and index in HBM also for the small workloads")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N > 1 "
+                    "on a box with fewer GPUs than ranks: ranks then share devices)")
     args = ap.parse_args()
 
     import torch
@@ -84,10 +86,19 @@ def main():
     assert world == args.gpus, "--gpus must equal WORLD_SIZE (launch N>1 with torch.distributed.run)"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
+    if args.backend != "nccl":
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
+
+    def note(msg):
+        if os.environ.get("GPUMAP_BENCH_VERBOSE"):
+            print("[bench rank %d] %s" % (rank, msg), file=sys.stderr, flush=True)
 
     w = dict(WORKLOADS[args.workload])
     if args.reads:
@@ -106,6 +117,7 @@ def main():
         g, lens, names = synth_device.make_genome(w["L"], w["seed"], n_seqs=w["n_seqs"], gc=w["gc"], repeat_rich=w["rich"])
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
+        note("sequences generated")
         if rank == 0:
             t0 = time.time()
             ctx = ma.Context.build_device(lens, local, keep_reference=want_cpu, device_ptr=g.data_ptr())
@@ -129,6 +141,7 @@ def main():
             meta = [bytes(hdr), int(dev.occ_bytes), int(dev.sa_bytes), int(dev.tables_bytes)]
         else:
             meta = [None, 0, 0, 0]
+        note("index ready, broadcasting")
         dist.broadcast_object_list(meta, src=0)
         bufs = []
         for i, nbytes in enumerate(meta[1:]):
@@ -139,6 +152,7 @@ def main():
                 t = torch.empty(nbytes, dtype=torch.uint8, device=torch.device("cuda", local))
             dist.broadcast(t, src=0)
             bufs.append(t)
+            note("broadcast of buffer %d done (%d bytes)" % (i, nbytes))
         torch.cuda.synchronize()
         if rank != 0:
             d = ma.DevIndex(bufs[0].data_ptr(), meta[1], bufs[1].data_ptr(), meta[2], bufs[2].data_ptr(), meta[3])
@@ -159,6 +173,7 @@ def main():
         codes, offs = synth.make_reads(seqs, w["reads"], w["m"], w["tau"], seed=read_seed)
     batch = ctx.upload(codes.reshape(-1), offs)
     t_setup = time.time() - t_setup
+    note("reads resident, timing")
 
     def barrier():
         torch.cuda.synchronize()
