@@ -218,8 +218,9 @@ def main():
             "stages_ms": {"search": c["ms_search"], "locate": c["ms_locate"], "order": c["ms_sort"],
                           "total": c["ms_total"]},
             "hits_per_batch": {"intervals": c["n_hits"], "located": c["n_locs"]},
-            "occupancy": {"loop_passes": c["loop_passes"], "child_passes": c["child_passes"],
-                          "lane_fill": (c["n_ext"] / (64.0 * c["loop_passes"])) if c["loop_passes"] else None},
+            "occupancy": {"loop_passes": c["loop_passes"], "continuations": c["continuations"],
+                          "steps_from_jump_table": c["jumped_steps"],
+                          "lane_fill": ((c["n_ext"] - c["jumped_steps"]) / (64.0 * c["loop_passes"])) if c["loop_passes"] else None},
             "setup_s": {"index_build": t_index, "index_built_on": "device" if on_device else "host", "upload_repack": t_upload, "rccl_broadcast": t_bcast,
                         "all": t_setup},
         }

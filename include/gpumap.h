@@ -211,7 +211,9 @@ int           gpumap_batch_counters(const gpumap_batch *batch, int64_t *n_hits, 
                                     int64_t *n_ext, float ms[4]);
 /* Occupancy figures of the last search (tuning aid; no counterpart in the reference):
 ** stats[0] = passes of the search loop summed over all wavefronts (n_ext / (64 * stats[0]) = share
-** of lanes that held a node), stats[1] = passes of the inner loop over children, [2..3] reserved. */
+** of lanes that held a node, once stats[2] is taken off n_ext), stats[1] = nodes pushed back as
+** continuations, stats[2] = extension steps of the reference schedule that the jump table stood in
+** for (they are part of n_ext), [3] reserved. */
 int           gpumap_batch_stats(const gpumap_batch *batch, int64_t stats[4]);
 void          gpumap_batch_free(gpumap_batch *batch);
 

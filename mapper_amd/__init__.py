@@ -233,7 +233,7 @@ class Batch:
         if lib().gpumap_batch_stats(self._h, st) != 0:
             raise GpumapError("gpumap_batch_stats failed")
         return dict(n_hits=nh.value, n_locs=nl.value, n_ext=ne.value, ms_search=ms[0], ms_locate=ms[1],
-                    ms_sort=ms[2], ms_total=ms[3], loop_passes=st[0], child_passes=st[1])
+                    ms_sort=ms[2], ms_total=ms[3], loop_passes=st[0], continuations=st[1], jumped_steps=st[2])
 
     def fetch(self):
         raw = _Hits()

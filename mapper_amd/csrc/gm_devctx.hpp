@@ -70,6 +70,9 @@ struct gpumap_ctx {
    int64_t ref_occ_words = 0;
    uint64_t c_host[8] = {0, 0, 0, 0, 0, 0, 0, 0};
    int64_t wil_cnt = 0;
+   // jump table of the leaf phases (k_build_jump): 4^jump_k entries of 16 bytes, nullptr = off
+   void *d_jump = nullptr;
+   int jump_k = 0;
    // launch shape
    int cu_count = 256;
    int waves_per_cu = 0;              // 0 = default (12)
@@ -89,3 +92,5 @@ struct gpumap_ctx {
 int gm_ctx_repack(gpumap_ctx *ctx, const uint64_t *d_ref_occ, const uint64_t *d_c, int64_t mark_intv,
                   const int64_t *seq_beg_host, int64_t seq_cnt);
 int gm_ctx_common_init(gpumap_ctx *ctx, int device);
+// (Re)builds the jump table for K-mers of k letters (k < 0: default for the text length; 0: none).
+int gm_ctx_build_jump(gpumap_ctx *ctx, int k);

@@ -70,6 +70,7 @@ extern "C" void gpumap_destroy(gpumap_ctx *ctx)
       if (ctx->d_tables) (void)hipFree(ctx->d_tables);
       if (ctx->d_sa) (void)hipFree(ctx->d_sa);
    }
+   if (ctx->d_jump) (void)hipFree(ctx->d_jump);
    if (ctx->d_ref_occ) (void)hipFree(ctx->d_ref_occ);
    if (ctx->d_text) (void)hipFree(ctx->d_text);
    if (ctx->d_sym_table) (void)hipFree(ctx->d_sym_table);
@@ -77,6 +78,30 @@ extern "C" void gpumap_destroy(gpumap_ctx *ctx)
    if (ctx->pin_arena) (void)hipHostFree(ctx->pin_arena);
    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
    delete ctx;
+}
+
+int gm_ctx_build_jump(gpumap_ctx *ctx, int k)
+{
+   if (ctx->d_jump) { HIP_TRY(hipFree(ctx->d_jump)); ctx->d_jump = nullptr; ctx->jump_k = 0; }
+   if (k < 0) {
+      // as many letters as keep the table below 1/16 of an entry per text position, at most 14 (4.3 GB)
+      k = 0;
+      while (k < 14 && ((int64_t)1 << (2 * (k + 1))) <= ctx->ix.n / 16) k++;
+      if (k < 4) k = 0;
+   }
+   GM_FAIL_IF(k > 14, "jump_k out of range.");
+   if (k == 0) return 0;
+   {
+      const int64_t entries = (int64_t)1 << (2 * k);
+      HIP_TRY(hipMalloc(&ctx->d_jump, 16 * (size_t)entries));
+      hipLaunchKernelGGL(k_build_jump, dim3((unsigned)cdiv(entries, 256)), dim3(256), 0, ctx->stream, ctx->ix, k, (uint4 *)ctx->d_jump);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      ctx->jump_k = k;
+   }
+   return 0;
+failure_return:
+   return -1;
 }
 
 int gm_ctx_repack(gpumap_ctx *ctx, const uint64_t *d_ref_occ, const uint64_t *d_c, int64_t mark_intv,
@@ -112,7 +137,7 @@ int gm_ctx_repack(gpumap_ctx *ctx, const uint64_t *d_ref_occ, const uint64_t *d_
    ix.tables = (const uint64_t *)ctx->d_tables;
    ix.sa = (const uint64_t *)ctx->d_sa;
    ix.seq_beg = (const int64_t *)((const uint64_t *)ctx->d_tables + TAB_SBASE + SYMS * ix.n_super);
-   return 0;
+   return gm_ctx_build_jump(ctx, getenv("GPUMAP_JUMP_K") ? atoi(getenv("GPUMAP_JUMP_K")) : -1);
 failure_return:
    return -1;
 }
@@ -235,6 +260,7 @@ extern "C" gpumap_ctx *gpumap_create_from_device(const gpumap_devindex *dev, con
    ctx->ix.tables = (const uint64_t *)ctx->d_tables;
    ctx->ix.sa = (const uint64_t *)ctx->d_sa;
    ctx->ix.seq_beg = (const int64_t *)((const uint64_t *)ctx->d_tables + TAB_SBASE + SYMS * h.n_super);
+   GM_FAIL_IF(gm_ctx_build_jump(ctx, getenv("GPUMAP_JUMP_K") ? atoi(getenv("GPUMAP_JUMP_K")) : -1) != 0, "cannot build the jump table.");
    return ctx;
 failure_return:
    gpumap_destroy(ctx);
@@ -246,6 +272,7 @@ extern "C" int gpumap_set_option(gpumap_ctx *ctx, const char *name, int64_t valu
    GM_FAIL_IF(ctx == nullptr || name == nullptr, "NULL argument.");
    if (!strcmp(name, "waves_per_cu")) { GM_FAIL_IF(value < 0 || value > 32, "waves_per_cu out of range."); ctx->waves_per_cu = (int)value; }
    else if (!strcmp(name, "pinned_results")) ctx->pinned_results = value != 0;
+   else if (!strcmp(name, "jump_k")) { HIP_TRY(hipSetDevice(ctx->device)); GM_FAIL_IF(gm_ctx_build_jump(ctx, (int)value) != 0, "cannot build the jump table."); }
    else if (!strcmp(name, "spill_nodes")) { GM_FAIL_IF(value < 0 || value > (1 << 22), "spill_nodes out of range."); ctx->spill_cap = value ? ((value + SPILL_CHUNK - 1) / SPILL_CHUNK) * SPILL_CHUNK : 16384; }
    else GM_FAIL("unknown option.");
    return 0;
@@ -501,6 +528,7 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
          A.n_reads = R; A.stride = b->stride; A.tau = tau;
          A.cursor = cnt + 0; A.hits = b->hits.as<Node>(); A.hit_cap = hit_cap; A.hit_count = cnt + 1; A.n_ext = cnt + 2;
          A.spill = ctx->spill.as<Node>(); A.spill_cap = (uint32_t)ctx->spill_cap; A.error = (int *)(cnt + 3); A.stats = cnt + 4;
+         A.jump = (const uint4 *)ctx->d_jump; A.jump_k = ctx->jump_k;
          if (R > 0) {
             hipLaunchKernelGGL(k_search, dim3((unsigned)n_wg), dim3(WG_THREADS), (size_t)ctx->ix.n_super * SYMS * 8, st, A);
             HIP_TRY(hipGetLastError());

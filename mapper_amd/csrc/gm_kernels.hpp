@@ -128,6 +128,34 @@ __global__ void k_query_all(IndexDev ix, int end, int64_t n, const int64_t *fp, 
    }
 }
 
+// Jump table: entry idx = the state of the exact right-to-left search of one K-mer from the root
+// interval, i.e. what the first K iterations of a leaf phase (seqsearch_bw with tau 0,
+// src/blocksearch.c:138-144, :440-496) compute for the query symbols s_0 (first, rightmost) .. s_{K-1},
+// idx = sum s_t << 2t.  16 bytes in the layout of a node's first four words: fp, rp, sz (40 bits each)
+// and d in the top byte: d = K, or, when sz = 0, the step at which the interval became empty (the
+// reference stops there, after d calls of bwt_query_all).  One thread per K-mer.
+__global__ void k_build_jump(IndexDev ix, int K, uint4 *table)
+{
+   const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+   if (idx >= ((int64_t)1 << (2 * K))) return;
+   uint64_t c[SYMS];
+   for (int j = 0; j < SYMS; j++) c[j] = ix.tables[TAB_C + j];
+   int64_t fp = 0, rp = 0, sz = ix.n;
+   int d = K;
+   for (int t = 0; t < K; t++) {
+      const int s = (int)((idx >> (2 * t)) & 3);
+      int64_t occ0[SYMS], occ1[SYMS], fpn[SYMS], rpn[SYMS], szn[SYMS];
+      rank_abs(ix, fp, occ0);
+      rank_abs(ix, fp + sz, occ1);
+      extend_all(rp, sz, occ0, occ1, c, fpn, rpn, szn);
+      if (szn[s] < 1) { sz = 0; d = t + 1; break; }
+      fp = fpn[s]; rp = rpn[s]; sz = szn[s];
+   }
+   table[idx] = make_uint4((uint32_t)fp, (uint32_t)rp, (uint32_t)sz,
+                           (uint32_t)((fp >> 32) & 0xff) | ((uint32_t)((rp >> 32) & 0xff) << 8) |
+                           ((uint32_t)((sz >> 32) & 0xff) << 16) | ((uint32_t)d << 24));
+}
+
 // sar_get (src/index_sar.c:92-118): entry i = bits [i*b, (i+1)*b) of the little-endian stream.
 __device__ inline int64_t sa_entry(const uint64_t *sa, int bits, int64_t i)
 {
@@ -198,7 +226,10 @@ struct SearchArgs {
    Node *spill;                 // [waves][spill_cap]
    uint32_t spill_cap;
    int *error;                  // set to 1 when a spill region overflows
-   unsigned long long *stats;   // [0] passes of the main loop over all waves, [1] continuations pushed
+   unsigned long long *stats;   // [0] passes of the main loop over all waves, [1] continuations pushed,
+                                // [2] extension steps the jump table stood in for
+   const uint4 *jump;           // jump table (k_build_jump) or nullptr
+   int jump_k;
 };
 
 // Selection by a per-lane index, written over values (not over the array) so that the arrays stay

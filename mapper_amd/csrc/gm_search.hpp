@@ -168,6 +168,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_search(SearchArgs A)
    uint32_t qword = 0;          // four query symbols around pos
    int qword_at = -1;           // pos >> 2 of the cached word, -1 = none
    unsigned long long ext_count = 0;
+   uint32_t jump_steps = 0;     // extension steps of this lane's seeds that the jump table stood in for
 
    for (;;) {
       // ------------------------------------------------------------ hand nodes to idle lanes
@@ -211,6 +212,27 @@ __global__ void __launch_bounds__(WG_THREADS) k_search(SearchArgs A)
                         sd.read = rd; sd.score = 0; sd.mm = (uint64_t)row << 56;
                         sd.sref = 0; sd.pos = sd.end = sd.tau = sd.diff = sd.phase = 0; sd.dash = sd.fw = false;
                         enter_phase(sd, leaf, A.phases[row * MAX_PHASES + leaf]);
+                        // The first K steps of a leaf are an exact search from the root interval: one look-up in
+                        // the jump table instead (counted as the steps the reference executes).  Not for a query N
+                        // among the K symbols (it follows all symbols), nor when the block has no letter left after.
+                        if (A.jump != nullptr && sd.pos - sd.end >= A.jump_k) {
+                           const uint8_t *qp = A.reads + (size_t)rd * A.stride + sd.pos;
+                           uint32_t idx = 0, bad = 0;
+                           for (int t = 0; t < A.jump_k; t++) {
+                              const uint32_t sym = qp[-t];
+                              bad |= sym & ~3u;
+                              idx |= (sym & 3u) << (2 * t);
+                           }
+                           if (!bad) {
+                              const uint4 e = A.jump[idx];
+                              sd.fp = (int64_t)e.x | ((int64_t)(e.w & 0xff) << 32);
+                              sd.rp = (int64_t)e.y | ((int64_t)((e.w >> 8) & 0xff) << 32);
+                              sd.sz = (int64_t)e.z | ((int64_t)((e.w >> 16) & 0xff) << 32);
+                              jump_steps += e.w >> 24;
+                              sd.pos -= A.jump_k;
+                              mk = sd.sz > 0;
+                           }
+                        }
                         pack_node(sd, packed);
                      }
                   }
@@ -354,10 +376,13 @@ __global__ void __launch_bounds__(WG_THREADS) k_search(SearchArgs A)
       }
    }
    if (hr.tail != hr.head) hit_flush(A, hr, lane, hr.tail - hr.head);
+   for (int o = 32; o > 0; o >>= 1) jump_steps += (uint32_t)__shfl_xor((int)jump_steps, o);
+   ext_count += jump_steps;
    if (lane == 0 && ext_count) {
       atomicAdd(A.n_ext, ext_count);
       atomicAdd(A.stats + 0, n_iter);
       atomicAdd(A.stats + 1, n_cont);
+      atomicAdd(A.stats + 2, (unsigned long long)jump_steps);
    }
 }
 

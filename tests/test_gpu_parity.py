@@ -85,6 +85,28 @@ def test_map_small_matches_reference_dump(small, tau):
     assert h.n_ext == d.n_ext
 
 
+@pytest.mark.parametrize("jump_k", [0, 4, 9, 14])
+def test_jump_table_changes_nothing(small, jump_k):
+    """The K-mer jump table of the leaf phases (k_build_jump) stands in for the first K extension steps:
+    hits and even the count of extension steps stay those of the reference schedule, for K-mers that
+    are absent from the text (the search dies inside the table), query N inside the K-mer (no jump) and
+    blocks shorter than K (no jump).  The golden dumps are those of the compiled reference."""
+    base, ctx, orc = small
+    ctx.set_option("jump_k", jump_k)
+    try:
+        reads = common.load_reads("small.reads.txt")
+        codes, offs = common.encode_reads(reads)
+        for tau in (0, 1, 2, 4):
+            ref = po.HitDump.load(os.path.join(common.GOLDEN, "small.tau%d.bin" % tau))
+            h = ctx.map_batch(codes, offs, tau, want_intervals=True)
+            assert np.array_equal(h.status, ref.status)
+            assert np.array_equal(h.located(), ref.located())
+            assert np.array_equal(h.intervals(), ref.intervals())
+            assert h.n_ext == orc.map_batch(codes, offs, tau, threads=2).n_ext
+    finally:
+        ctx.set_option("jump_k", -1)
+
+
 @pytest.mark.parametrize("tau", [0, 1, 2])
 def test_map_repeats_matches_reference_dump(workdir, tau):
     base = common.build_golden_index(workdir, "repeats")
