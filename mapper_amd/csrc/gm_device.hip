@@ -548,9 +548,7 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
       // ---- K3 locate: sizes -> scan -> flat gather
       const int64_t H = b->n_hits;
       int64_t L = 0;
-      HIP_TRY(b->read_cnt.ensure(4 * (size_t)(R + 1)));
       HIP_TRY(b->read_first.ensure(8 * (size_t)(R + 1)));
-      HIP_TRY(hipMemsetAsync(b->read_cnt.p, 0, 4 * (size_t)(R + 1), st));
       if (H > 0) {
          HIP_TRY(b->hit_sizes.ensure(8 * (size_t)(H + 1)));
          HIP_TRY(b->hit_off.ensure(8 * (size_t)(H + 1)));
@@ -573,18 +571,12 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
          HIP_TRY(b->keys.ensure(8 * (size_t)L));
          HIP_TRY(b->keys_alt.ensure(8 * (size_t)L));
          hipLaunchKernelGGL(k_expand_hits, dim3((unsigned)cdiv(L, 256)), dim3(256), 0, st, ctx->ix, b->hits.as<const Node>(), H,
-                            b->hit_off.as<const int64_t>(), L, pos_bits, b->keys.as<unsigned long long>(),
-                            b->read_cnt.as<unsigned int>());
+                            b->hit_off.as<const int64_t>(), L, pos_bits, b->keys.as<unsigned long long>());
          HIP_TRY(hipGetLastError());
       }
       HIP_TRY(hipEventRecord(b->ev[2], st));
       // ---- order: reads in input order, text positions ascending inside a read
-      {
-         size_t tmp = 0;
-         HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, b->read_cnt.as<unsigned int>(), b->read_first.as<int64_t>(), (int)(R + 1), st));
-         HIP_TRY(ctx->cub_tmp.ensure(tmp));
-         HIP_TRY(hipcub::DeviceScan::ExclusiveSum(ctx->cub_tmp.p, tmp, b->read_cnt.as<unsigned int>(), b->read_first.as<int64_t>(), (int)(R + 1), st));
-      }
+      if (L == 0) HIP_TRY(hipMemsetAsync(b->read_first.p, 0, 8 * (size_t)(R + 1), st));
       if (L > 0) {
          hipcub::DoubleBuffer<unsigned long long> db(b->keys.as<unsigned long long>(), b->keys_alt.as<unsigned long long>());
          size_t tmp = 0;
@@ -594,6 +586,8 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
          for (DevBuf *x : {&b->loc_read, &b->loc_pos, &b->loc_fwd, &b->loc_seq, &b->loc_seqpos}) HIP_TRY(x->ensure(8 * (size_t)L));
          HIP_TRY(b->loc_strand.ensure((size_t)L));
          HIP_TRY(b->loc_score.ensure((size_t)L));
+         hipLaunchKernelGGL(k_read_first, dim3((unsigned)cdiv(R + 1, 256)), dim3(256), 0, st, (const unsigned long long *)db.Current(),
+                            L, R, pos_bits + 4, b->read_first.as<int64_t>());
          hipLaunchKernelGGL(k_unpack_locs, dim3((unsigned)cdiv(L, 256)), dim3(256), 0, st, ctx->ix,
                             (const unsigned long long *)db.Current(), L, pos_bits, b->loc_read.as<int64_t>(),
                             b->loc_pos.as<int64_t>(), b->loc_fwd.as<int64_t>(), b->loc_seq.as<int64_t>(),

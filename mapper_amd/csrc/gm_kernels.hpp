@@ -319,19 +319,38 @@ __global__ void k_hit_sizes(const Node *hits, int64_t n_hits, int64_t *sizes)
    sizes[i] = (int64_t)hits[i].w[2] | ((int64_t)((hits[i].w[3] >> 16) & 0xff) << 32);
 }
 
-__global__ void k_expand_hits(IndexDev ix, const Node *hits, int64_t n_hits, const int64_t *hit_off,
-                              int64_t n_locs, int pos_bits, unsigned long long *keys,
-                              unsigned int *read_cnt)
+__global__ void __launch_bounds__(256) k_expand_hits(IndexDev ix, const Node *hits, int64_t n_hits, const int64_t *hit_off,
+                                                     int64_t n_locs, int pos_bits, unsigned long long *keys)
 {
-   int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+   // A block covers 256 consecutive slots.  Every hit holds at least one slot, so the hits of the block
+   // lie within 256 entries of the hit of its first slot: one long binary search per block, a short
+   // one (over a cached window) per thread.
+   __shared__ int64_t s_lo;
+   const int64_t t0 = blockIdx.x * (int64_t)256, t = t0 + threadIdx.x;
+   if (threadIdx.x == 0) {
+      int64_t lo = 0, hi = n_hits;             // last h with hit_off[h] <= t0
+      while (hi - lo > 1) { int64_t mid = (lo + hi) >> 1; if (hit_off[mid] <= t0) lo = mid; else hi = mid; }
+      s_lo = lo;
+   }
+   __syncthreads();
    if (t >= n_locs) return;
-   int64_t lo = 0, hi = n_hits;             // last h with hit_off[h] <= t
+   int64_t lo = s_lo, hi = min(lo + 257, n_hits);
    while (hi - lo > 1) { int64_t mid = (lo + hi) >> 1; if (hit_off[mid] <= t) lo = mid; else hi = mid; }
    NodeR h;
    unpack_node(hits[lo], h);
    int64_t pos = sa_entry(ix.sa, ix.sar_bits, h.fp + (t - hit_off[lo]));
    keys[t] = ((unsigned long long)h.read << (pos_bits + 4)) | ((unsigned long long)pos << 4) | (unsigned long long)h.score;
-   atomicAdd(read_cnt + h.read, 1u);
+}
+
+// CSR offsets of the reads into the sorted keys: first key of read r = lower bound of r << shift.
+__global__ void k_read_first(const unsigned long long *keys, int64_t n_locs, int64_t n_reads, int shift, int64_t *read_first)
+{
+   int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+   if (r > n_reads) return;
+   const unsigned long long want = (unsigned long long)r << shift;
+   int64_t lo = 0, hi = n_locs;                // first t with keys[t] >= want
+   while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (keys[mid] < want) lo = mid + 1; else hi = mid; }
+   read_first[r] = lo;
 }
 
 // Sorted keys -> structure of arrays; strand and coordinates by the rule of txt_pos_to_str
