@@ -568,8 +568,7 @@ extern "C" gpumap_ctx *gpumap_build_device(const uint8_t *codes, int codes_on_de
       // ---- rank blocks
       GM_FAIL_IF(gm_ctx_repack(ctx, (const uint64_t *)ref_occ, (const uint64_t *)d_c, MARK_INTV, seq_beg.data(), seq_cnt) != 0, "cannot repack the Occ table.");
       if (!keep_reference) {
-         HIP_TRY(hipFree(ctx->d_ref_occ)); ctx->d_ref_occ = nullptr; ctx->ref_occ_words = 0;
-         HIP_TRY(hipFree(ctx->d_text)); ctx->d_text = nullptr;
+         HIP_TRY(hipFree(ctx->d_ref_occ)); ctx->d_ref_occ = nullptr; ctx->ref_occ_words = 0;      // the text stays: k_verify reads it
       }
    }
    tmp.release();

@@ -165,6 +165,12 @@ struct NodeR {      // unpacked, in registers
 
 constexpr int META_DASH = 6, META_SCORE = 7, META_SREF = 10, META_FW = 13, META_END = 14, META_TAU = 22,
               META_DIFF = 25, META_FIRST = 28;
+// Entries of the output list of k_search: a finished hit (an interval of the whole read), or, bit 31 set,
+// a node whose interval holds one suffix and that k_verify finishes against the text.  k_verify turns
+// it into a located hit (first = LOCATED: the fp field holds the text position of the read) or
+// empties it (sz = 0).
+constexpr int META_CAND = 31;
+constexpr uint32_t LOCATED = 7;
 
 constexpr int PHASE_FINAL = 63;
 
@@ -218,6 +224,7 @@ GM_HD uint32_t phase_entry(int start, int end, int fw, int tau, int diff, int ne
 
 struct PhaseBuilder {
    uint32_t entry[MAX_PHASES];
+   uint8_t lo[MAX_PHASES];        // lowest query position already matched when the phase starts (forward phases)
    int n_leaf = 0, n_ext = 0, tau_total;
    bool error = false;
    // returns nothing; fills entries.  cont = phase entered when a path completes [pos,end]
@@ -225,6 +232,7 @@ struct PhaseBuilder {
    {
       if (pos < 0 || pos > end || end < 0) { error = true; return; }     // src/blocksearch.c:125-127
       if (blocks == 1) {                                                 // :138-144
+         lo[n_leaf] = 0;                                                  // backward phases: lo = node position + 1
          entry[n_leaf++] = phase_entry(end, pos, 0, 0, 0, cont);
          return;
       }
@@ -234,6 +242,7 @@ struct PhaseBuilder {
       int ext_l = tau_total + 1 + n_ext++, ext_r = tau_total + 1 + n_ext++;
       entry[ext_l] = phase_entry(pos_r, end, 1, blocks - 1, 0, cont);     // :159-162
       entry[ext_r] = phase_entry(end_l, pos, 0, blocks - 1, blk_l, cont); // :167-170
+      lo[ext_l] = (uint8_t)pos; lo[ext_r] = 0;
       build(pos, end_l, blk_l, ext_l);                                    // :157
       if (error) return;
       build(pos_r, end, blk_r, ext_r);                                    // :165
@@ -241,14 +250,15 @@ struct PhaseBuilder {
 };
 
 // Fills `table[0 .. 3*tau]`; returns false where the reference returns -1 for this (m, tau).
-inline bool build_phase_table(int m, int tau, uint32_t *table)
+// lo (optional): per phase, the lowest query position matched before a forward phase starts.
+inline bool build_phase_table(int m, int tau, uint32_t *table, uint8_t *lo = nullptr)
 {
    if (m < 1 || m > MAX_READ || tau < 0 || tau > MAX_TAU) return false;
    PhaseBuilder b;
    b.tau_total = tau;
    b.build(0, m - 1, tau + 1, PHASE_FINAL);
    if (b.error) return false;
-   for (int i = 0; i < 3 * tau + 1; i++) table[i] = b.entry[i];
+   for (int i = 0; i < 3 * tau + 1; i++) { table[i] = b.entry[i]; if (lo) lo[i] = b.lo[i]; }
    return true;
 }
 

@@ -70,6 +70,10 @@ struct gpumap_ctx {
    int64_t ref_occ_words = 0;
    uint64_t c_host[8] = {0, 0, 0, 0, 0, 0, 0, 0};
    int64_t wil_cnt = 0;
+   // nodes whose interval holds one suffix are finished against the text (k_verify) when the text is in
+   // HBM (d_text) and the caller wants located hits only
+   bool verify = true;
+   bool owns_text = true;
    // jump table of the leaf phases (k_build_jump): 4^jump_k entries of 16 bytes, nullptr = off
    void *d_jump = nullptr;
    int jump_k = 0;

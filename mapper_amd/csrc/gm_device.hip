@@ -18,7 +18,7 @@ struct gpumap_batch {
    int64_t n_reads = 0;
    int stride = 0;
    std::vector<int64_t> offsets;     // host copy (n_reads + 1)
-   DevBuf reads, read_len, len_row, phases, phase_rec, status;
+   DevBuf reads, read_len, len_row, phases, phase_rec, phase_lo, status;
    DevBuf hits, hit_sizes, hit_off, keys, keys_alt, read_cnt, read_first;
    DevBuf loc_read, loc_pos, loc_fwd, loc_seq, loc_seqpos, loc_strand, loc_score;
    DevBuf hkeys, hkeys_alt, hidx, hidx_alt, hit_read, hit_fp, hit_rp, hit_sz, hit_dp, hit_score, hit_align;
@@ -31,7 +31,7 @@ struct gpumap_batch {
    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
    void release()
    {
-      for (DevBuf *b : {&reads, &read_len, &len_row, &phases, &phase_rec, &status, &hits, &hit_sizes, &hit_off, &keys, &keys_alt,
+      for (DevBuf *b : {&reads, &read_len, &len_row, &phases, &phase_rec, &phase_lo, &status, &hits, &hit_sizes, &hit_off, &keys, &keys_alt,
                         &read_cnt, &read_first, &loc_read, &loc_pos, &loc_fwd, &loc_seq, &loc_seqpos, &loc_strand,
                         &loc_score, &hkeys, &hkeys_alt, &hidx, &hidx_alt, &hit_read, &hit_fp, &hit_rp, &hit_sz,
                         &hit_dp, &hit_score, &hit_align})
@@ -72,7 +72,7 @@ extern "C" void gpumap_destroy(gpumap_ctx *ctx)
    }
    if (ctx->d_jump) (void)hipFree(ctx->d_jump);
    if (ctx->d_ref_occ) (void)hipFree(ctx->d_ref_occ);
-   if (ctx->d_text) (void)hipFree(ctx->d_text);
+   if (ctx->d_text && ctx->owns_text) (void)hipFree(ctx->d_text);
    if (ctx->d_sym_table) (void)hipFree(ctx->d_sym_table);
    for (DevBuf *b : {&ctx->spill, &ctx->counters, &ctx->op_in, &ctx->op_out, &ctx->cub_tmp}) b->release();
    if (ctx->pin_arena) (void)hipHostFree(ctx->pin_arena);
@@ -187,6 +187,10 @@ extern "C" gpumap_ctx *gpumap_create(const gpumap_index_view *v, int device)
       HIP_TRY(hipFree(d_c)); d_c = nullptr;
       memcpy(ctx->c_host, v->c, 8 * (SYMS + 1));
       ctx->wil_cnt = v->wil_cnt;
+      if (v->text) {        // the text lets k_verify finish unique nodes; without it the search runs on the Occ table alone
+         HIP_TRY(hipMalloc(&ctx->d_text, (size_t)v->txt_len));
+         HIP_TRY(hipMemcpy(ctx->d_text, v->text, (size_t)v->txt_len, hipMemcpyHostToDevice));
+      }
    }
    (void)d_seq;
    return ctx;
@@ -272,6 +276,7 @@ extern "C" int gpumap_set_option(gpumap_ctx *ctx, const char *name, int64_t valu
    GM_FAIL_IF(ctx == nullptr || name == nullptr, "NULL argument.");
    if (!strcmp(name, "waves_per_cu")) { GM_FAIL_IF(value < 0 || value > 32, "waves_per_cu out of range."); ctx->waves_per_cu = (int)value; }
    else if (!strcmp(name, "pinned_results")) ctx->pinned_results = value != 0;
+   else if (!strcmp(name, "verify")) ctx->verify = value != 0;
    else if (!strcmp(name, "jump_k")) { HIP_TRY(hipSetDevice(ctx->device)); GM_FAIL_IF(gm_ctx_build_jump(ctx, (int)value) != 0, "cannot build the jump table."); }
    else if (!strcmp(name, "spill_nodes")) { GM_FAIL_IF(value < 0 || value > (1 << 22), "spill_nodes out of range."); ctx->spill_cap = value ? ((value + SPILL_CHUNK - 1) / SPILL_CHUNK) * SPILL_CHUNK : 16384; }
    else GM_FAIL("unknown option.");
@@ -478,26 +483,32 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
       // ---- schedule: one phase-table row per read length present (src/blocksearch.c:138-170)
       std::vector<uint8_t> len_row(MAX_READ + 1, 0xff);
       std::vector<uint32_t> phases, phase_rec;
+      std::vector<uint8_t> phase_lo;
       int rows = 0;
       for (int m = 1; m <= MAX_READ; m++) {
          if (!b->length_seen[m]) continue;
          uint32_t tab[MAX_PHASES];
+         uint8_t lo_tab[MAX_PHASES];
          memset(tab, 0, sizeof tab);
-         if (!build_phase_table(m, tau, tab)) continue;        // the reference returns -1 for this length
+         memset(lo_tab, 0, sizeof lo_tab);
+         if (!build_phase_table(m, tau, tab, lo_tab)) continue;        // the reference returns -1 for this length
          GM_FAIL_IF(rows >= 255, "too many distinct read lengths.");
          len_row[m] = (uint8_t)rows++;
          phases.insert(phases.end(), tab, tab + MAX_PHASES);
+         phase_lo.insert(phase_lo.end(), lo_tab, lo_tab + MAX_PHASES);
          for (int p = 0; p < MAX_PHASES; p++) {
             uint32_t x = 0, y = 0;
             if (p < 3 * tau + 1) phase_record(tab, p, x, y);
             phase_rec.push_back(x); phase_rec.push_back(y);
          }
       }
-      if (phases.empty()) { phases.assign(MAX_PHASES, 0); phase_rec.assign(2 * MAX_PHASES, 0); }
+      if (phases.empty()) { phases.assign(MAX_PHASES, 0); phase_rec.assign(2 * MAX_PHASES, 0); phase_lo.assign(MAX_PHASES, 0); }
       HIP_TRY(b->len_row.ensure(MAX_READ + 1));
       HIP_TRY(b->phases.ensure(4 * phases.size()));
       HIP_TRY(b->phase_rec.ensure(4 * phase_rec.size()));
       HIP_TRY(hipMemcpyAsync(b->phase_rec.p, phase_rec.data(), 4 * phase_rec.size(), hipMemcpyHostToDevice, st));
+      HIP_TRY(b->phase_lo.ensure(phase_lo.size()));
+      HIP_TRY(hipMemcpyAsync(b->phase_lo.p, phase_lo.data(), phase_lo.size(), hipMemcpyHostToDevice, st));
       HIP_TRY(hipMemcpyAsync(b->len_row.p, len_row.data(), MAX_READ + 1, hipMemcpyHostToDevice, st));
       HIP_TRY(hipMemcpyAsync(b->phases.p, phases.data(), 4 * phases.size(), hipMemcpyHostToDevice, st));
       if (R > 0) {
@@ -514,7 +525,9 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
       HIP_TRY(ctx->spill.ensure((size_t)n_waves * (size_t)ctx->spill_cap * sizeof(Node)));
       unsigned long long *cnt = ctx->counters.as<unsigned long long>();   // [0] cursor [1] hits [2] n_ext [3] error
       unsigned long long host_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      size_t hit_cap = std::max<size_t>((size_t)1 << 16, (size_t)R * 2);
+      // interval output needs the final interval of every hit: no short cut through the text then
+      const bool use_verify = ctx->verify && ctx->d_text != nullptr && !want_intervals;
+      size_t hit_cap = std::max<size_t>((size_t)1 << 16, (size_t)R * (use_verify ? (size_t)tau + 3 : 2));
       HIP_TRY(hipEventRecord(b->ev[0], st));
       for (int attempt = 0; attempt < 2; attempt++) {
          HIP_TRY(b->hits.ensure(hit_cap * sizeof(Node)));
@@ -529,6 +542,7 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
          A.cursor = cnt + 0; A.hits = b->hits.as<Node>(); A.hit_cap = hit_cap; A.hit_count = cnt + 1; A.n_ext = cnt + 2;
          A.spill = ctx->spill.as<Node>(); A.spill_cap = (uint32_t)ctx->spill_cap; A.error = (int *)(cnt + 3); A.stats = cnt + 4;
          A.jump = (const uint4 *)ctx->d_jump; A.jump_k = ctx->jump_k;
+         A.verify = use_verify ? 1 : 0;
          if (R > 0) {
             hipLaunchKernelGGL(k_search, dim3((unsigned)n_wg), dim3(WG_THREADS), (size_t)ctx->ix.n_super * SYMS * 8, st, A);
             HIP_TRY(hipGetLastError());
@@ -539,6 +553,17 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
          if (host_cnt[1] <= hit_cap) break;
          GM_FAIL_IF(attempt == 1, "hit list overflowed twice.");
          hit_cap = (size_t)host_cnt[1];
+      }
+      if (use_verify && host_cnt[1] > 0) {
+         VerifyArgs V;
+         V.ix = ctx->ix; V.text = (const uint8_t *)ctx->d_text;
+         V.reads = b->reads.as<const uint8_t>(); V.read_len = b->read_len.as<const uint16_t>();
+         V.phase_rec = b->phase_rec.as<const uint2>(); V.phase_lo = b->phase_lo.as<const uint8_t>();
+         V.list = b->hits.as<Node>(); V.n_list = (int64_t)host_cnt[1]; V.stride = b->stride; V.n_ext = cnt + 2;
+         hipLaunchKernelGGL(k_verify, dim3((unsigned)cdiv(V.n_list, 256)), dim3(256), 0, st, V);
+         HIP_TRY(hipGetLastError());
+         HIP_TRY(hipMemcpyAsync(host_cnt, cnt, 64, hipMemcpyDeviceToHost, st));
+         HIP_TRY(hipStreamSynchronize(st));
       }
       HIP_TRY(hipEventRecord(b->ev[1], st));
       b->n_hits = (int64_t)host_cnt[1];

@@ -230,7 +230,93 @@ struct SearchArgs {
                                 // [2] extension steps the jump table stood in for
    const uint4 *jump;           // jump table (k_build_jump) or nullptr
    int jump_k;
+   int verify;                  // nodes with sz == 1 leave as candidates for k_verify
 };
+
+// ------------------------------------------------------------------------------------------------
+// k_verify: the rest of the search of a node whose interval holds ONE suffix.  From there on the
+// reference's recursion (seqsearch_* / seqdash_*, src/blocksearch.c:184-496) is a walk along one
+// place of the text: at every position exactly one child interval is non-empty (the text symbol; none
+// at a separator), so the walk is replayed on the text itself -- same rules, same hits, and the same
+// count of bwt_query_all calls (one per position visited, the one at which the path dies included).
+// One suffix-array entry and a window of the text replace one Occ line per letter.
+// One thread per entry of the output list of k_search; entries that are not candidates are left alone.
+// ------------------------------------------------------------------------------------------------
+struct VerifyArgs {
+   IndexDev ix;
+   const uint8_t  *text;        // [n] codes 0..5
+   const uint8_t  *reads;
+   const uint16_t *read_len;
+   const uint2    *phase_rec;   // [rows][MAX_PHASES]
+   const uint8_t  *phase_lo;    // [rows][MAX_PHASES]
+   Node *list;
+   int64_t n_list;
+   int stride;
+   unsigned long long *n_ext;
+};
+
+__global__ void __launch_bounds__(256) k_verify(VerifyArgs A)
+{
+   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+   uint32_t steps = 0;
+   if (i < A.n_list && (A.list[i].w[5] >> META_CAND)) {
+      Node nd = A.list[i];
+      const int64_t fp = (int64_t)nd.w[0] | ((int64_t)(nd.w[3] & 0xff) << 32);
+      int pos = (int)(nd.w[3] >> 24);
+      uint32_t meta = nd.w[5] & ~(1u << META_CAND);
+      const uint32_t read = nd.w[4];
+      const int row = (int)(nd.w[7] >> 24);
+      const uint8_t *q = A.reads + (size_t)read * A.stride;
+      int phase = (int)(meta & 63);
+      bool fw = (meta >> META_FW) & 1, dash = (meta >> META_DASH) & 1;
+      int end = (meta >> META_END) & 255, tau = (meta >> META_TAU) & 7, diff = (meta >> META_DIFF) & 7;
+      int score = (meta >> META_SCORE) & 7, sref = (meta >> META_SREF) & 7;
+      const int lo = fw ? A.phase_lo[row * MAX_PHASES + phase] : pos + 1;      // lowest query position matched so far
+      const int64_t p0 = sa_entry(A.ix.sa, A.ix.sar_bits, fp) - lo;              // text position of query position 0
+      bool alive = true, final = false;
+      while (alive && !final) {
+         // one phase: positions pos .. end in the phase's direction
+         for (;;) {
+            steps++;
+            const int64_t tp = p0 + pos;
+            const int t = (tp < 0 || tp >= A.ix.n) ? SYMS : A.text[tp];
+            const int qc = q[pos];
+            if (t == SYMS) { alive = false; break; }                 // separator: no child at all
+            const bool mis = qc != UNKNOWN && t != qc;                // text N against a base costs one; query N is free
+            if (dash) {
+               if (mis) { alive = false; break; }
+            } else {
+               const int s = score + (mis ? 1 : 0);
+               if (s > tau) { alive = false; break; }
+               if (s == tau) { if (s - sref < diff) { alive = false; break; } dash = true; }
+               else if (pos == end && s - sref < diff) { alive = false; break; }
+               score = s;
+            }
+            if (pos == end) break;
+            pos += fw ? 1 : -1;
+         }
+         if (!alive) break;
+         const uint2 rec = A.phase_rec[row * MAX_PHASES + phase];
+         if (rec.y >> 8) { final = true; break; }
+         phase = (int)(rec.x & 63);
+         fw = (rec.x >> META_FW) & 1; dash = (rec.x >> META_DASH) & 1;
+         end = (rec.x >> META_END) & 255; tau = (rec.x >> META_TAU) & 7; diff = (rec.x >> META_DIFF) & 7;
+         sref = score;
+         pos = (int)(rec.y & 255);
+      }
+      // located hit: the text position of the read's first letter in the fp field, one suffix; or nothing
+      const int64_t where = final ? p0 : 0;
+      nd.w[0] = (uint32_t)where;
+      nd.w[2] = final ? 1u : 0u;
+      nd.w[3] = (uint32_t)((where >> 32) & 0xff);
+      nd.w[5] = (uint32_t)phase | ((uint32_t)score << META_SCORE) | (LOCATED << META_FIRST);
+      uint4 *d = reinterpret_cast<uint4 *>(A.list + i);
+      d[0] = make_uint4(nd.w[0], nd.w[1], nd.w[2], nd.w[3]);
+      d[1] = make_uint4(nd.w[4], nd.w[5], nd.w[6], nd.w[7]);
+   }
+   for (int o = 32; o > 0; o >>= 1) steps += (uint32_t)__shfl_xor((int)steps, o);
+   if ((threadIdx.x & 63) == 0 && steps) atomicAdd(A.n_ext, (unsigned long long)steps);
+}
 
 // Selection by a per-lane index, written over values (not over the array) so that the arrays stay
 // in registers: a select chain over array elements is turned into an indexed stack access.
@@ -322,23 +408,25 @@ __global__ void k_hit_sizes(const Node *hits, int64_t n_hits, int64_t *sizes)
 __global__ void __launch_bounds__(256) k_expand_hits(IndexDev ix, const Node *hits, int64_t n_hits, const int64_t *hit_off,
                                                      int64_t n_locs, int pos_bits, unsigned long long *keys)
 {
-   // A block covers 256 consecutive slots.  Every hit holds at least one slot, so the hits of the block
-   // lie within 256 entries of the hit of its first slot: one long binary search per block, a short
-   // one (over a cached window) per thread.
-   __shared__ int64_t s_lo;
+   // A block covers 256 consecutive slots: two long binary searches per block (the hits of its first and
+   // last slot), a short one per thread between them.  Entries without slots (emptied by k_verify) share
+   // their offset with the next entry; "last h with hit_off[h] <= t" skips them.
+   __shared__ int64_t s_lo, s_hi;
    const int64_t t0 = blockIdx.x * (int64_t)256, t = t0 + threadIdx.x;
-   if (threadIdx.x == 0) {
-      int64_t lo = 0, hi = n_hits;             // last h with hit_off[h] <= t0
-      while (hi - lo > 1) { int64_t mid = (lo + hi) >> 1; if (hit_off[mid] <= t0) lo = mid; else hi = mid; }
-      s_lo = lo;
+   if (threadIdx.x == 0 || threadIdx.x == 255) {
+      const int64_t tt = threadIdx.x == 0 ? t0 : min(t0 + 255, n_locs - 1);
+      int64_t lo = 0, hi = n_hits;             // last h with hit_off[h] <= tt
+      while (hi - lo > 1) { int64_t mid = (lo + hi) >> 1; if (hit_off[mid] <= tt) lo = mid; else hi = mid; }
+      if (threadIdx.x == 0) s_lo = lo; else s_hi = lo;
    }
    __syncthreads();
    if (t >= n_locs) return;
-   int64_t lo = s_lo, hi = min(lo + 257, n_hits);
+   int64_t lo = s_lo, hi = s_hi + 1;
    while (hi - lo > 1) { int64_t mid = (lo + hi) >> 1; if (hit_off[mid] <= t) lo = mid; else hi = mid; }
    NodeR h;
    unpack_node(hits[lo], h);
-   int64_t pos = sa_entry(ix.sa, ix.sar_bits, h.fp + (t - hit_off[lo]));
+   // an entry k_verify located carries the text position itself; an interval is read from the suffix array
+   int64_t pos = h.first == (int)LOCATED ? h.fp : sa_entry(ix.sa, ix.sar_bits, h.fp + (t - hit_off[lo]));
    keys[t] = ((unsigned long long)h.read << (pos_bits + 4)) | ((unsigned long long)pos << 4) | (unsigned long long)h.score;
 }
 

@@ -364,15 +364,18 @@ __global__ void __launch_bounds__(WG_THREADS) k_search(SearchArgs A)
       } else {
          have = false;
       }
-      if (__any(emit)) {
+      // A node whose interval has shrunk to one suffix leaves the search: k_verify finishes it against the
+      // text (one suffix-array entry and a window of the text instead of one Occ line per letter).
+      const bool toverify = A.verify && have && !emit && sz == 1;
+      if (__any(emit || toverify)) {
          Node out;
          out.w[0] = (uint32_t)fp; out.w[1] = (uint32_t)rp; out.w[2] = (uint32_t)sz;
          out.w[3] = (uint32_t)((fp >> 32) & 0xff) | ((uint32_t)((rp >> 32) & 0xff) << 8) |
-                    ((uint32_t)((sz >> 32) & 0xff) << 16);
-         out.w[4] = read; out.w[5] = meta;
+                    ((uint32_t)((sz >> 32) & 0xff) << 16) | ((uint32_t)pos << 24);
+         out.w[4] = read; out.w[5] = meta | ((uint32_t)toverify << META_CAND);
          out.w[6] = (uint32_t)mm; out.w[7] = (uint32_t)(mm >> 32);
-         hit_emit(A, hr, emit, out, lane);
-         if (emit) have = false;
+         hit_emit(A, hr, emit || toverify, out, lane);
+         if (emit || toverify) have = false;
       }
    }
    if (hr.tail != hr.head) hit_flush(A, hr, lane, hr.tail - hr.head);
