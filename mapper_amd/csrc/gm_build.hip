@@ -500,7 +500,8 @@ extern "C" gpumap_ctx *gpumap_build_device(const uint8_t *codes, int codes_on_de
       }
       HIP_TRY(A.get(&d_seq_beg, (size_t)seq_cnt));
       HIP_TRY(hipMemcpy(d_seq_beg, seq_beg.data(), 8 * (size_t)seq_cnt, hipMemcpyHostToDevice));
-      HIP_TRY(hipMalloc((void **)&text, (size_t)n));
+      HIP_TRY(hipMalloc((void **)&text, (size_t)n + 16));                    // k_verify reads whole words
+      HIP_TRY(hipMemset(text + n, SYMS, 16));
       ctx->d_text = text;                                   // released by gpumap_destroy (or below)
       hipLaunchKernelGGL(k_build_text, dim3(grid_for(n, 256)), dim3(256), 0, st, d_codes, (const int64_t *)d_seq_beg, seq_cnt, tlen0, text);
       HIP_TRY(hipGetLastError());

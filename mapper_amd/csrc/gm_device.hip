@@ -188,7 +188,8 @@ extern "C" gpumap_ctx *gpumap_create(const gpumap_index_view *v, int device)
       memcpy(ctx->c_host, v->c, 8 * (SYMS + 1));
       ctx->wil_cnt = v->wil_cnt;
       if (v->text) {        // the text lets k_verify finish unique nodes; without it the search runs on the Occ table alone
-         HIP_TRY(hipMalloc(&ctx->d_text, (size_t)v->txt_len));
+         HIP_TRY(hipMalloc(&ctx->d_text, (size_t)v->txt_len + 16));          // k_verify reads whole words
+         HIP_TRY(hipMemset((char *)ctx->d_text + v->txt_len, SYMS, 16));
          HIP_TRY(hipMemcpy(ctx->d_text, v->text, (size_t)v->txt_len, hipMemcpyHostToDevice));
       }
    }

@@ -274,9 +274,29 @@ __global__ void __launch_bounds__(256) k_verify(VerifyArgs A)
       const int lo = fw ? A.phase_lo[row * MAX_PHASES + phase] : pos + 1;      // lowest query position matched so far
       const int64_t p0 = sa_entry(A.ix.sa, A.ix.sar_bits, fp) - lo;              // text position of query position 0
       bool alive = true, final = false;
+      // Four letters at a time while nothing happens: no mismatch, no N, no separator, and the phase's last
+      // position not among them (the rules of that position are applied letter by letter below).  The
+      // text is read as aligned words; its buffer is padded by 16 bytes.
+      const uint32_t *q32 = reinterpret_cast<const uint32_t *>(q);
+      const uint32_t *t32 = reinterpret_cast<const uint32_t *>(A.text);
+      const int sh = (int)(p0 & 3);
+      const bool inside = p0 >= 0 && p0 + A.read_len[read] <= A.ix.n;
       while (alive && !final) {
          // one phase: positions pos .. end in the phase's direction
          for (;;) {
+            if (inside) {
+               const int j = fw ? pos : pos - 3;
+               if ((fw ? ((pos & 3) == 0 && pos + 3 < end) : ((pos & 3) == 3 && pos - 3 > end))) {
+                  const uint32_t qw = q32[j >> 2];
+                  const int64_t b = (p0 + j) >> 2;
+                  const uint32_t tw = __builtin_amdgcn_alignbyte(t32[b + 1], t32[b], (uint32_t)sh);
+                  if (qw == tw && ((qw | tw) & 0x04040404u) == 0) {
+                     steps += 4;
+                     pos += fw ? 4 : -4;
+                     continue;
+                  }
+               }
+            }
             steps++;
             const int64_t tp = p0 + pos;
             const int t = (tp < 0 || tp >= A.ix.n) ? SYMS : A.text[tp];
