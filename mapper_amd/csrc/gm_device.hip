@@ -23,7 +23,7 @@ struct gpumap_batch {
    DevBuf loc_read, loc_pos, loc_fwd, loc_seq, loc_seqpos, loc_strand, loc_score;
    DevBuf hkeys, hkeys_alt, hidx, hidx_alt, hit_read, hit_fp, hit_rp, hit_sz, hit_dp, hit_score, hit_align;
    bool length_seen[MAX_READ + 1];
-   int64_t n_hits = 0, n_locs = 0, n_ext = 0;
+   int64_t n_hits = 0, n_real = 0, n_locs = 0, n_ext = 0;
    int64_t stats[4] = {0, 0, 0, 0};
    bool have_intervals = false, ran = false;
    int tau = 0;
@@ -54,7 +54,7 @@ int gm_ctx_common_init(gpumap_ctx *ctx, int device)
    HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
    HIP_TRY(hipMalloc((void **)&ctx->d_sym_table, 256));
    HIP_TRY(hipMemcpy(ctx->d_sym_table, ctx->sym_table, 256, hipMemcpyHostToDevice));
-   HIP_TRY(ctx->counters.ensure(64));
+   HIP_TRY(ctx->counters.ensure(8 * (8 + 64)));      // 8 counters + 64 partial sums of k_verify
    return 0;
 failure_return:
    return -1;
@@ -525,7 +525,8 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
       const int64_t n_waves = (int64_t)n_wg * WG_WAVES;
       HIP_TRY(ctx->spill.ensure((size_t)n_waves * (size_t)ctx->spill_cap * sizeof(Node)));
       unsigned long long *cnt = ctx->counters.as<unsigned long long>();   // [0] cursor [1] hits [2] n_ext [3] error
-      unsigned long long host_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      unsigned long long host_cnt[8 + 64];
+      memset(host_cnt, 0, sizeof host_cnt);
       // interval output needs the final interval of every hit: no short cut through the text then
       const bool use_verify = ctx->verify && ctx->d_text != nullptr && !want_intervals;
       size_t hit_cap = std::max<size_t>((size_t)1 << 16, (size_t)R * (use_verify ? (size_t)tau + 3 : 2));
@@ -533,7 +534,7 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
       for (int attempt = 0; attempt < 2; attempt++) {
          HIP_TRY(b->hits.ensure(hit_cap * sizeof(Node)));
          hit_cap = b->hits.cap / sizeof(Node);
-         HIP_TRY(hipMemsetAsync(cnt, 0, 64, st));
+         HIP_TRY(hipMemsetAsync(cnt, 0, sizeof host_cnt, st));
          SearchArgs A;
          A.ix = ctx->ix;
          A.reads = b->reads.as<const uint8_t>(); A.read_len = b->read_len.as<const uint16_t>();
@@ -544,6 +545,11 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
          A.spill = ctx->spill.as<Node>(); A.spill_cap = (uint32_t)ctx->spill_cap; A.error = (int *)(cnt + 3); A.stats = cnt + 4;
          A.jump = (const uint4 *)ctx->d_jump; A.jump_k = ctx->jump_k;
          A.verify = use_verify ? 1 : 0;
+         {
+            const int rpr = 64 / (tau + 1);
+            int64_t k = R / std::max<int64_t>(1, n_waves * 8 * rpr);           // at least 8 reservations per wave: balance at the end
+            A.cursor_chunk = (uint32_t)(rpr * std::min<int64_t>(16, std::max<int64_t>(1, k)));
+         }
          if (R > 0) {
             hipLaunchKernelGGL(k_search, dim3((unsigned)n_wg), dim3(WG_THREADS), (size_t)ctx->ix.n_super * SYMS * 8, st, A);
             HIP_TRY(hipGetLastError());
@@ -553,21 +559,24 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
          GM_FAIL_IF(host_cnt[3] != 0, "search spill region overflowed (raise 'spill_nodes').");
          if (host_cnt[1] <= hit_cap) break;
          GM_FAIL_IF(attempt == 1, "hit list overflowed twice.");
-         hit_cap = (size_t)host_cnt[1];
+         hit_cap = (size_t)host_cnt[1] + (size_t)n_waves * HIT_CHUNK;           // pieces are reserved whole, in another order next time
       }
       if (use_verify && host_cnt[1] > 0) {
          VerifyArgs V;
          V.ix = ctx->ix; V.text = (const uint8_t *)ctx->d_text;
          V.reads = b->reads.as<const uint8_t>(); V.read_len = b->read_len.as<const uint16_t>();
          V.phase_rec = b->phase_rec.as<const uint2>(); V.phase_lo = b->phase_lo.as<const uint8_t>();
-         V.list = b->hits.as<Node>(); V.n_list = (int64_t)host_cnt[1]; V.stride = b->stride; V.n_ext = cnt + 2;
-         hipLaunchKernelGGL(k_verify, dim3((unsigned)cdiv(V.n_list, 256)), dim3(256), 0, st, V);
+         V.list = b->hits.as<Node>(); V.n_list = (int64_t)host_cnt[1]; V.stride = b->stride; V.n_ext = cnt + 8;
+         const int vbd = b->stride <= 128 ? 256 : 128;                  // 2 * stride bytes of LDS per thread, at most 64 KB
+         hipLaunchKernelGGL(k_verify, dim3((unsigned)cdiv(V.n_list, vbd)), dim3(vbd), (size_t)2 * b->stride * vbd, st, V);
          HIP_TRY(hipGetLastError());
-         HIP_TRY(hipMemcpyAsync(host_cnt, cnt, 64, hipMemcpyDeviceToHost, st));
+         HIP_TRY(hipMemcpyAsync(host_cnt, cnt, sizeof host_cnt, hipMemcpyDeviceToHost, st));
          HIP_TRY(hipStreamSynchronize(st));
+         for (int k = 0; k < 64; k++) host_cnt[2] += host_cnt[8 + k];
       }
       HIP_TRY(hipEventRecord(b->ev[1], st));
-      b->n_hits = (int64_t)host_cnt[1];
+      b->n_hits = (int64_t)host_cnt[1];            // entries of the list, holes included
+      b->n_real = (int64_t)host_cnt[7];            // hits (and candidates handed to k_verify) among them
       b->n_ext = (int64_t)host_cnt[2];
       for (int i = 0; i < 4; i++) b->stats[i] = (int64_t)host_cnt[4 + i];
 
@@ -635,8 +644,9 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
          HIP_TRY(hipcub::DeviceRadixSort::SortPairs(ctx->cub_tmp.p, tmp, dk, dv, (int)H, 0, 64, st));
          for (DevBuf *x : {&b->hit_read, &b->hit_fp, &b->hit_rp, &b->hit_sz, &b->hit_dp, &b->hit_score}) HIP_TRY(x->ensure(8 * (size_t)H));
          HIP_TRY(b->hit_align.ensure(32 * (size_t)H));
-         hipLaunchKernelGGL(k_unpack_hits, dim3((unsigned)cdiv(H, 256)), dim3(256), 0, st, b->hits.as<const Node>(),
-                            (const unsigned int *)dv.Current(), H, b->reads.as<const uint8_t>(), b->read_len.as<const uint16_t>(),
+         // the holes of the list sorted last: the first n_real entries are the hits
+         hipLaunchKernelGGL(k_unpack_hits, dim3((unsigned)cdiv(std::max<int64_t>(b->n_real, 1), 256)), dim3(256), 0, st, b->hits.as<const Node>(),
+                            (const unsigned int *)dv.Current(), b->n_real, b->reads.as<const uint8_t>(), b->read_len.as<const uint16_t>(),
                             b->stride, b->hit_read.as<int64_t>(), b->hit_fp.as<int64_t>(), b->hit_rp.as<int64_t>(),
                             b->hit_sz.as<int64_t>(), b->hit_dp.as<int64_t>(), b->hit_score.as<int64_t>(), b->hit_align.as<uint64_t>());
          HIP_TRY(hipGetLastError());
@@ -659,7 +669,7 @@ extern "C" int gpumap_batch_counters(const gpumap_batch *b, int64_t *n_hits, int
 {
    GM_FAIL_IF(b == nullptr, "argument 'batch' is NULL.");
    GM_FAIL_IF(!b->ran, "batch has not been run.");
-   if (n_hits) *n_hits = b->n_hits;
+   if (n_hits) *n_hits = b->n_real;
    if (n_locs) *n_locs = b->n_locs;
    if (n_ext) *n_ext = b->n_ext;
    if (ms) for (int i = 0; i < 4; i++) ms[i] = b->ms[i];
@@ -734,7 +744,7 @@ extern "C" int gpumap_batch_fetch(gpumap_ctx *ctx, gpumap_batch *b, gpumap_hits 
    HIP_TRY(hipSetDevice(ctx->device));
    {
       hipStream_t st = ctx->stream;
-      const int64_t R = b->n_reads, L = b->n_locs, H = b->have_intervals ? b->n_hits : 0;
+      const int64_t R = b->n_reads, L = b->n_locs, H = b->have_intervals ? b->n_real : 0;
       FetchDst d;
       if (ctx->pinned_results) {
          size_t need = 16 * 256 + 8 * (size_t)(2 * R + 1) + 42 * (size_t)L + 80 * (size_t)H;

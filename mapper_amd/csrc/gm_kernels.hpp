@@ -227,10 +227,11 @@ struct SearchArgs {
    uint32_t spill_cap;
    int *error;                  // set to 1 when a spill region overflows
    unsigned long long *stats;   // [0] passes of the main loop over all waves, [1] continuations pushed,
-                                // [2] extension steps the jump table stood in for
+                                // [2] extension steps the jump table stood in for, [3] entries of the list that are not holes
    const uint4 *jump;           // jump table (k_build_jump) or nullptr
    int jump_k;
    int verify;                  // nodes with sz == 1 leave as candidates for k_verify
+   uint32_t cursor_chunk;       // reads a wave reserves per atomic on the cursor (a multiple of its refill)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -252,11 +253,20 @@ struct VerifyArgs {
    Node *list;
    int64_t n_list;
    int stride;
-   unsigned long long *n_ext;
+   unsigned long long *n_ext;   // [64] partial sums (one hot address would serialise the waves)
 };
 
+// The query row and the text window of a candidate are first copied into LDS as words aligned with
+// each other (all loads of a thread in flight together: one memory round trip instead of one per word
+// walked), word w of thread t at [w * blockDim + t] (every lane its own bank).  The walk then goes a
+// word at a time while nothing happens, jumps to the first letter where something does (mismatch, N,
+// separator), and applies the rules letter by letter only there.
 __global__ void __launch_bounds__(256) k_verify(VerifyArgs A)
 {
+   extern __shared__ uint32_t s_words[];                  // [2][W][blockDim]: query words, then text words
+   const int BD = (int)blockDim.x, tid = (int)threadIdx.x;
+   const int W = A.stride >> 2;
+   uint32_t *sq = s_words + tid, *st = s_words + W * BD + tid;
    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
    uint32_t steps = 0;
    if (i < A.n_list && (A.list[i].w[5] >> META_CAND)) {
@@ -266,41 +276,63 @@ __global__ void __launch_bounds__(256) k_verify(VerifyArgs A)
       uint32_t meta = nd.w[5] & ~(1u << META_CAND);
       const uint32_t read = nd.w[4];
       const int row = (int)(nd.w[7] >> 24);
-      const uint8_t *q = A.reads + (size_t)read * A.stride;
+      const int m = A.read_len[read];
       int phase = (int)(meta & 63);
       bool fw = (meta >> META_FW) & 1, dash = (meta >> META_DASH) & 1;
       int end = (meta >> META_END) & 255, tau = (meta >> META_TAU) & 7, diff = (meta >> META_DIFF) & 7;
       int score = (meta >> META_SCORE) & 7, sref = (meta >> META_SREF) & 7;
       const int lo = fw ? A.phase_lo[row * MAX_PHASES + phase] : pos + 1;      // lowest query position matched so far
       const int64_t p0 = sa_entry(A.ix.sa, A.ix.sar_bits, fp) - lo;              // text position of query position 0
+      {
+         const uint32_t *q32 = reinterpret_cast<const uint32_t *>(A.reads + (size_t)read * A.stride);
+         const int nw = (m + 3) >> 2;
+         for (int w = 0; w < nw; w++) sq[w * BD] = q32[w];
+         if (p0 >= 0 && p0 + 4 * nw <= A.ix.n) {
+            const uint32_t *t32 = reinterpret_cast<const uint32_t *>(A.text) + (p0 >> 2);   // the text buffer is padded
+            const uint32_t sh = (uint32_t)(p0 & 3);
+            uint32_t prev = t32[0];
+            for (int w = 0; w < nw; w++) {
+               const uint32_t next = t32[w + 1];
+               st[w * BD] = __builtin_amdgcn_alignbyte(next, prev, sh);
+               prev = next;
+            }
+         } else {
+            for (int w = 0; w < nw; w++) {              // a window over an end of the text: separators outside
+               uint32_t v = 0;
+               for (int k = 0; k < 4; k++) {
+                  const int64_t tp = p0 + 4 * w + k;
+                  v |= (uint32_t)((tp < 0 || tp >= A.ix.n) ? SYMS : A.text[tp]) << (8 * k);
+               }
+               st[w * BD] = v;
+            }
+         }
+      }
       bool alive = true, final = false;
-      // Four letters at a time while nothing happens: no mismatch, no N, no separator, and the phase's last
-      // position not among them (the rules of that position are applied letter by letter below).  The
-      // text is read as aligned words; its buffer is padded by 16 bytes.
-      const uint32_t *q32 = reinterpret_cast<const uint32_t *>(q);
-      const uint32_t *t32 = reinterpret_cast<const uint32_t *>(A.text);
-      const int sh = (int)(p0 & 3);
-      const bool inside = p0 >= 0 && p0 + A.read_len[read] <= A.ix.n;
       while (alive && !final) {
          // one phase: positions pos .. end in the phase's direction
          for (;;) {
-            if (inside) {
-               const int j = fw ? pos : pos - 3;
-               if ((fw ? ((pos & 3) == 0 && pos + 3 < end) : ((pos & 3) == 3 && pos - 3 > end))) {
-                  const uint32_t qw = q32[j >> 2];
-                  const int64_t b = (p0 + j) >> 2;
-                  const uint32_t tw = __builtin_amdgcn_alignbyte(t32[b + 1], t32[b], (uint32_t)sh);
-                  if (qw == tw && ((qw | tw) & 0x04040404u) == 0) {
-                     steps += 4;
-                     pos += fw ? 4 : -4;
-                     continue;
-                  }
+            const int w = pos >> 2, b = pos & 3;
+            const uint32_t qw = sq[w * BD], tw = st[w * BD];
+            const bool last_word = (end >> 2) == w;
+            const int hi_b = fw ? (last_word ? (end & 3) : 3) : b, lo_b = fw ? b : (last_word ? (end & 3) : 0);
+            const uint32_t mask = (0xffffffffu >> (8 * (3 - hi_b))) & (0xffffffffu << (8 * lo_b));
+            const uint32_t ev = ((qw ^ tw) | ((qw | tw) & 0x04040404u)) & mask;
+            if (ev == 0) {                               // plain matches up to the end of the word or of the phase
+               steps += (uint32_t)(hi_b - lo_b + 1);
+               if (last_word) {
+                  pos = end;
+                  if (!dash && score - sref < diff) alive = false;       // the rule of the phase's last position
+                  break;
                }
+               pos = fw ? (w + 1) * 4 : w * 4 - 1;
+               continue;
             }
-            steps++;
-            const int64_t tp = p0 + pos;
-            const int t = (tp < 0 || tp >= A.ix.n) ? SYMS : A.text[tp];
-            const int qc = q[pos];
+            // plain matches up to the first letter where something happens, then that letter by the rules
+            const int e = fw ? ((__ffs((int)ev) - 1) >> 3) : (3 - (__clz((int)ev) >> 3));
+            const int skipped = fw ? e - b : b - e;
+            steps += (uint32_t)skipped + 1;
+            pos += fw ? skipped : -skipped;
+            const int t = (int)((tw >> (8 * e)) & 0xff), qc = (int)((qw >> (8 * e)) & 0xff);
             if (t == SYMS) { alive = false; break; }                 // separator: no child at all
             const bool mis = qc != UNKNOWN && t != qc;                // text N against a base costs one; query N is free
             if (dash) {
@@ -335,7 +367,7 @@ __global__ void __launch_bounds__(256) k_verify(VerifyArgs A)
       d[1] = make_uint4(nd.w[4], nd.w[5], nd.w[6], nd.w[7]);
    }
    for (int o = 32; o > 0; o >>= 1) steps += (uint32_t)__shfl_xor((int)steps, o);
-   if ((threadIdx.x & 63) == 0 && steps) atomicAdd(A.n_ext, (unsigned long long)steps);
+   if ((threadIdx.x & 63) == 0 && steps) atomicAdd(A.n_ext + (blockIdx.x & 63), (unsigned long long)steps);
 }
 
 // Selection by a per-lane index, written over values (not over the array) so that the arrays stay
@@ -492,7 +524,8 @@ __global__ void k_hit_keys(const Node *hits, int64_t n_hits, unsigned long long 
    if (i >= n_hits) return;
    NodeR h;
    unpack_node(hits[i], h);
-   keys[i] = ((unsigned long long)h.read << 40) | (unsigned long long)h.fp;   // reads < 2^24 per run, fp < 2^40
+   // reads < 2^24 per run, fp < 2^40; holes of the list (sz = 0) sort behind every hit
+   keys[i] = h.sz > 0 ? (((unsigned long long)h.read << 40) | (unsigned long long)h.fp) : ~0ull;
    idx[i] = (unsigned int)i;
 }
 

@@ -31,28 +31,57 @@ namespace gm {
 constexpr int STAGE_SLOT_U4 = 5;     // staging slot per lane, in 16-byte units (4 used + 1 pad)
 constexpr int HITBUF = 64;           // finished nodes staged per wave before they go to the global list
 
-// Finished nodes are staged in a per-wave LDS ring and leave it when the next ones would not fit: one
-// atomic on the global counter and one contiguous store of up to 2 KB per flush.  (One atomic per emitting
-// pass serialises all waves on one address: about 10 ns per atomic, which was the whole kernel time.)
+// Finished nodes are staged in a per-wave LDS ring and leave it when the next ones would not fit, into
+// a piece of the global list that the wave has reserved for itself: HIT_CHUNK entries per atomic on
+// the list's counter.  Every atomic on that one address costs all waves about 10 ns (one per emitting
+// pass was the whole kernel time once; one per flush still a third of it).  What a wave leaves unused
+// of its last piece is written as empty entries (sz = 0): the list has holes, its consumers skip them.
+constexpr uint32_t HIT_CHUNK = 512;
 struct HitRing {
    Node *ring;
    uint32_t head, tail;
+   unsigned long long out_base;      // the reserved piece: next free entry, entries left
+   uint32_t out_left;
+   unsigned long long n_real;        // entries written that are not holes
 };
+
+__device__ __forceinline__ void hit_reserve(const SearchArgs &A, HitRing &hr, int lane)
+{
+   unsigned long long base = 0;
+   if (lane == 0) base = atomicAdd(A.hit_count, (unsigned long long)HIT_CHUNK);
+   hr.out_base = __shfl(base, 0);
+   hr.out_left = HIT_CHUNK;
+}
 
 __device__ __forceinline__ void hit_flush(const SearchArgs &A, HitRing &hr, int lane, uint32_t n)
 {
-   unsigned long long base = 0;
-   if (lane == 0) base = atomicAdd(A.hit_count, (unsigned long long)n);
-   base = __shfl(base, 0);
-   if ((uint32_t)lane < n && base + lane < A.hit_cap) {
-      Node t;
-      lds_load_node<HITBUF>(hr.ring, hr.head + lane, t);
-      uint4 *d = reinterpret_cast<uint4 *>(A.hits + base + lane);
-      d[0] = make_uint4(t.w[0], t.w[1], t.w[2], t.w[3]);
-      d[1] = make_uint4(t.w[4], t.w[5], t.w[6], t.w[7]);
+   hr.n_real += n;
+   while (n > 0) {
+      if (hr.out_left == 0) hit_reserve(A, hr, lane);
+      const uint32_t k = min(n, hr.out_left);
+      if ((uint32_t)lane < k && hr.out_base + lane < A.hit_cap) {
+         Node t;
+         lds_load_node<HITBUF>(hr.ring, hr.head + lane, t);
+         uint4 *d = reinterpret_cast<uint4 *>(A.hits + hr.out_base + lane);
+         d[0] = make_uint4(t.w[0], t.w[1], t.w[2], t.w[3]);
+         d[1] = make_uint4(t.w[4], t.w[5], t.w[6], t.w[7]);
+      }
+      hr.head += k; hr.out_base += k; hr.out_left -= k; n -= k;
    }
-   hr.head += n;
    wave_sync();
+}
+
+// End of the wave: the ring goes out, the rest of the reserved piece becomes holes.
+__device__ __forceinline__ void hit_finish(const SearchArgs &A, HitRing &hr, int lane)
+{
+   if (hr.tail != hr.head) hit_flush(A, hr, lane, hr.tail - hr.head);
+   for (uint32_t i = lane; i < hr.out_left; i += 64)
+      if (hr.out_base + i < A.hit_cap) {
+         uint4 *d = reinterpret_cast<uint4 *>(A.hits + hr.out_base + i);
+         d[0] = make_uint4(0, 0, 0, 0);
+         d[1] = make_uint4(0, 0, 0, 0);
+      }
+   if (lane == 0 && hr.n_real) atomicAdd(A.stats + 3, hr.n_real);
 }
 
 // Converged call: lanes with `flag` append `nd`.
@@ -150,7 +179,10 @@ __global__ void __launch_bounds__(WG_THREADS) k_search(SearchArgs A)
    HitRing hr;
    hr.ring = s_hit[wid];
    hr.head = hr.tail = 0;
+   hr.out_base = 0; hr.out_left = 0; hr.n_real = 0;
    unsigned long long n_iter = 0, n_cont = 0;
+   unsigned long long res_base = 0;      // reads reserved from the global cursor (A.cursor_chunk per atomic)
+   uint32_t res_left = 0;
 
    const int seeds_per = A.tau + 1;
    const int reads_per_refill = 64 / seeds_per;
@@ -190,13 +222,19 @@ __global__ void __launch_bounds__(WG_THREADS) k_search(SearchArgs A)
                wq.top += SPILL_CHUNK;
             } else if (reads_left) {
                // Admit reads: one seed per leaf block of the schedule (src/blocksearch.c:138-144).
-               unsigned long long base = 0;
-               if (lane == 0) base = atomicAdd(A.cursor, (unsigned long long)reads_per_refill);
-               base = __shfl(base, 0);
-               if (base >= (unsigned long long)A.n_reads) {
+               if (res_left == 0) {
+                  unsigned long long got_base = 0;
+                  if (lane == 0) got_base = atomicAdd(A.cursor, (unsigned long long)A.cursor_chunk);
+                  res_base = __shfl(got_base, 0);
+                  res_left = res_base < (unsigned long long)A.n_reads
+                                ? (uint32_t)min((unsigned long long)A.cursor_chunk, (unsigned long long)A.n_reads - res_base) : 0u;
+               }
+               if (res_left == 0) {
                   reads_left = false;
                } else {
-                  int got = (int)min((unsigned long long)reads_per_refill, (unsigned long long)A.n_reads - base);
+                  const int got = (int)min((uint32_t)reads_per_refill, res_left);
+                  const unsigned long long base = res_base;
+                  res_base += (unsigned long long)got; res_left -= (uint32_t)got;
                   int r = lane / seeds_per, leaf = lane - r * seeds_per;
                   bool mk = r < got;
                   Node packed;
@@ -378,7 +416,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_search(SearchArgs A)
          if (emit || toverify) have = false;
       }
    }
-   if (hr.tail != hr.head) hit_flush(A, hr, lane, hr.tail - hr.head);
+   hit_finish(A, hr, lane);
    for (int o = 32; o > 0; o >>= 1) jump_steps += (uint32_t)__shfl_xor((int)jump_steps, o);
    ext_count += jump_steps;
    if (lane == 0 && ext_count) {
