@@ -138,15 +138,18 @@ def main():
         t0 = time.time()
         if rank == 0:
             dev, hdr = ctx.export()
-            meta = [bytes(hdr), int(dev.occ_bytes), int(dev.sa_bytes), int(dev.tables_bytes)]
+            meta = [bytes(hdr), int(dev.occ_bytes), int(dev.sa_bytes), int(dev.tables_bytes), int(dev.text_bytes)]
         else:
-            meta = [None, 0, 0, 0]
+            meta = [None, 0, 0, 0, 0]
         note("index ready, broadcasting")
         dist.broadcast_object_list(meta, src=0)
         bufs = []
         for i, nbytes in enumerate(meta[1:]):
+            if nbytes == 0:
+                bufs.append(None)
+                continue
             if rank == 0:
-                ptr = (dev.occ_blocks, dev.sa_words, dev.tables)[i]
+                ptr = (dev.occ_blocks, dev.sa_words, dev.tables, dev.text)[i]
                 t = torch.as_tensor(_DevPtr(ptr, nbytes), device=torch.device("cuda", local))
             else:
                 t = torch.empty(nbytes, dtype=torch.uint8, device=torch.device("cuda", local))
@@ -155,7 +158,8 @@ def main():
             note("broadcast of buffer %d done (%d bytes)" % (i, nbytes))
         torch.cuda.synchronize()
         if rank != 0:
-            d = ma.DevIndex(bufs[0].data_ptr(), meta[1], bufs[1].data_ptr(), meta[2], bufs[2].data_ptr(), meta[3])
+            d = ma.DevIndex(bufs[0].data_ptr(), meta[1], bufs[1].data_ptr(), meta[2], bufs[2].data_ptr(), meta[3],
+                            bufs[3].data_ptr() if bufs[3] is not None else None, meta[4])
             ctx = ma.Context.from_device(d, meta[0], local, keep=bufs)
         keep = bufs
         t_bcast = time.time() - t0
@@ -219,8 +223,10 @@ def main():
                           "total": c["ms_total"]},
             "hits_per_batch": {"intervals": c["n_hits"], "located": c["n_locs"]},
             "occupancy": {"loop_passes": c["loop_passes"], "continuations": c["continuations"],
-                          "steps_from_jump_table": c["jumped_steps"],
-                          "lane_fill": ((c["n_ext"] - c["jumped_steps"]) / (64.0 * c["loop_passes"])) if c["loop_passes"] else None},
+                          "steps_from_jump_table": c["jumped_steps"], "steps_replayed_on_text": c["verify_steps"],
+                          "steps_on_occ_table": c["n_ext"] - c["jumped_steps"] - c["verify_steps"],
+                          "lane_fill": ((c["n_ext"] - c["jumped_steps"] - c["verify_steps"]) / (64.0 * c["loop_passes"]))
+                          if c["loop_passes"] else None},
             "setup_s": {"index_build": t_index, "index_built_on": "device" if on_device else "host", "upload_repack": t_upload, "rccl_broadcast": t_bcast,
                         "all": t_setup},
         }

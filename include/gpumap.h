@@ -119,6 +119,8 @@ typedef struct {
    void   *occ_blocks;  int64_t occ_bytes;   /* repacked Occ blocks               */
    void   *sa_words;    int64_t sa_bytes;    /* packed suffix array (verbatim)    */
    void   *tables;      int64_t tables_bytes;/* superblock counts, C, seq_beg ... */
+   void   *text;        int64_t text_bytes;  /* text codes + 16 bytes of padding; NULL / 0: none (the
+                                             ** search then stays on the Occ table, see k_verify)  */
 } gpumap_devindex;
 size_t      gpumap_devindex_header_size(void);
 int         gpumap_devindex_export(const gpumap_ctx *ctx, gpumap_devindex *out, void *header);
@@ -209,12 +211,14 @@ int           gpumap_batch_fetch(gpumap_ctx *ctx, gpumap_batch *batch, gpumap_hi
 /* Counters of the last run without copying hits: n_hits, n_locs, n_ext, and stage times (ms). */
 int           gpumap_batch_counters(const gpumap_batch *batch, int64_t *n_hits, int64_t *n_locs,
                                     int64_t *n_ext, float ms[4]);
-/* Occupancy figures of the last search (tuning aid; no counterpart in the reference):
-** stats[0] = passes of the search loop summed over all wavefronts (n_ext / (64 * stats[0]) = share
-** of lanes that held a node, once stats[2] is taken off n_ext), stats[1] = nodes pushed back as
-** continuations, stats[2] = extension steps of the reference schedule that the jump table stood in
-** for (they are part of n_ext), [3] reserved. */
-int           gpumap_batch_stats(const gpumap_batch *batch, int64_t stats[4]);
+/* Work figures of the last search (tuning aid; no counterpart in the reference).  n_ext, the
+** bwt_query_all calls of the reference schedule, is made of three parts: steps k_search executed on
+** the Occ table, steps the jump table stood in for (stats[2]) and steps k_verify replayed on the text
+** (stats[4]).  stats[0] = passes of the search loop summed over all wavefronts (64 nodes each when
+** full), stats[1] = nodes pushed back as continuations, stats[3] = entries k_search wrote to its
+** output list (hits and candidates for k_verify), stats[5] = length of that list with the unused ends
+** of the wavefronts' reservations, [6..7] reserved. */
+int           gpumap_batch_stats(const gpumap_batch *batch, int64_t stats[8]);
 void          gpumap_batch_free(gpumap_batch *batch);
 
 /* ------------------------------------------------------------------------------------------

@@ -38,7 +38,8 @@ class IndexView(C.Structure):
 
 class DevIndex(C.Structure):
     _fields_ = [("occ_blocks", C.c_void_p), ("occ_bytes", C.c_int64), ("sa_words", C.c_void_p),
-                ("sa_bytes", C.c_int64), ("tables", C.c_void_p), ("tables_bytes", C.c_int64)]
+                ("sa_bytes", C.c_int64), ("tables", C.c_void_p), ("tables_bytes", C.c_int64),
+                ("text", C.c_void_p), ("text_bytes", C.c_int64)]
 
 
 class _Hits(C.Structure):
@@ -229,11 +230,12 @@ class Batch:
         ms = (C.c_float * 4)()
         if lib().gpumap_batch_counters(self._h, C.byref(nh), C.byref(nl), C.byref(ne), ms) != 0:
             raise GpumapError("gpumap_batch_counters failed")
-        st = (_I64 * 4)()
+        st = (_I64 * 8)()
         if lib().gpumap_batch_stats(self._h, st) != 0:
             raise GpumapError("gpumap_batch_stats failed")
         return dict(n_hits=nh.value, n_locs=nl.value, n_ext=ne.value, ms_search=ms[0], ms_locate=ms[1],
-                    ms_sort=ms[2], ms_total=ms[3], loop_passes=st[0], continuations=st[1], jumped_steps=st[2])
+                    ms_sort=ms[2], ms_total=ms[3], loop_passes=st[0], continuations=st[1], jumped_steps=st[2], list_entries=st[3],
+                    verify_steps=st[4], list_length=st[5])
 
     def fetch(self):
         raw = _Hits()

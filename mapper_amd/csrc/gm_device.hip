@@ -24,7 +24,7 @@ struct gpumap_batch {
    DevBuf hkeys, hkeys_alt, hidx, hidx_alt, hit_read, hit_fp, hit_rp, hit_sz, hit_dp, hit_score, hit_align;
    bool length_seen[MAX_READ + 1];
    int64_t n_hits = 0, n_real = 0, n_locs = 0, n_ext = 0;
-   int64_t stats[4] = {0, 0, 0, 0};
+   int64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
    bool have_intervals = false, ran = false;
    int tau = 0;
    float ms[4] = {0, 0, 0, 0};
@@ -222,6 +222,7 @@ extern "C" int gpumap_devindex_export(const gpumap_ctx *ctx, gpumap_devindex *ou
       out->occ_blocks = ctx->d_occ; out->occ_bytes = ctx->occ_bytes;
       out->sa_words = ctx->d_sa; out->sa_bytes = ctx->sa_bytes;
       out->tables = ctx->d_tables; out->tables_bytes = ctx->tables_bytes;
+      out->text = ctx->d_text; out->text_bytes = ctx->d_text ? ctx->ix.n + 16 : 0;
       DevIndexHeader h;
       memset(&h, 0, sizeof h);
       h.magic = DEVINDEX_MAGIC;
@@ -257,6 +258,7 @@ extern "C" gpumap_ctx *gpumap_create_from_device(const gpumap_devindex *dev, con
    memcpy(ctx->com_table, h.com_table, 8);
    GM_FAIL_IF(gm_ctx_common_init(ctx, device) != 0, "cannot initialise the device context.");
    ctx->d_occ = dev->occ_blocks; ctx->d_sa = dev->sa_words; ctx->d_tables = dev->tables;
+   if (dev->text != nullptr && dev->text_bytes >= h.n + 16) { ctx->d_text = dev->text; ctx->owns_text = false; }
    ctx->occ_bytes = dev->occ_bytes; ctx->sa_bytes = dev->sa_bytes; ctx->tables_bytes = dev->tables_bytes;
    ctx->sar_len = h.sar_len; ctx->tables_words = h.tables_words;
    ctx->ix.n = h.n; ctx->ix.n_blocks = h.n_blocks; ctx->ix.n_super = h.n_super;
@@ -561,6 +563,7 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
          GM_FAIL_IF(attempt == 1, "hit list overflowed twice.");
          hit_cap = (size_t)host_cnt[1] + (size_t)n_waves * HIT_CHUNK;           // pieces are reserved whole, in another order next time
       }
+      unsigned long long verify_steps = 0;
       if (use_verify && host_cnt[1] > 0) {
          VerifyArgs V;
          V.ix = ctx->ix; V.text = (const uint8_t *)ctx->d_text;
@@ -572,13 +575,15 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
          HIP_TRY(hipGetLastError());
          HIP_TRY(hipMemcpyAsync(host_cnt, cnt, sizeof host_cnt, hipMemcpyDeviceToHost, st));
          HIP_TRY(hipStreamSynchronize(st));
-         for (int k = 0; k < 64; k++) host_cnt[2] += host_cnt[8 + k];
+         for (int k = 0; k < 64; k++) { host_cnt[2] += host_cnt[8 + k]; verify_steps += host_cnt[8 + k]; }
       }
       HIP_TRY(hipEventRecord(b->ev[1], st));
       b->n_hits = (int64_t)host_cnt[1];            // entries of the list, holes included
       b->n_real = (int64_t)host_cnt[7];            // hits (and candidates handed to k_verify) among them
       b->n_ext = (int64_t)host_cnt[2];
       for (int i = 0; i < 4; i++) b->stats[i] = (int64_t)host_cnt[4 + i];
+      b->stats[4] = (int64_t)verify_steps;
+      b->stats[5] = (int64_t)host_cnt[1];
 
       // ---- K3 locate: sizes -> scan -> flat gather
       const int64_t H = b->n_hits;
@@ -678,11 +683,11 @@ failure_return:
    return -1;
 }
 
-extern "C" int gpumap_batch_stats(const gpumap_batch *b, int64_t stats[4])
+extern "C" int gpumap_batch_stats(const gpumap_batch *b, int64_t stats[8])
 {
    GM_FAIL_IF(b == nullptr || stats == nullptr, "NULL argument.");
    GM_FAIL_IF(!b->ran, "batch has not been run.");
-   for (int i = 0; i < 4; i++) stats[i] = b->stats[i];
+   for (int i = 0; i < 8; i++) stats[i] = b->stats[i];
    return 0;
 failure_return:
    return -1;

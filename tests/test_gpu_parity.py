@@ -85,6 +85,73 @@ def test_map_small_matches_reference_dump(small, tau):
     assert h.n_ext == d.n_ext
 
 
+@pytest.mark.parametrize("tau", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("name", ["small", "repeats"])
+def test_verify_path_matches_reference_dump(workdir, name, tau):
+    """Located hits only (want_intervals = 0): nodes whose interval holds one suffix are finished by k_verify
+    against the text instead of on the Occ table.  Same located hits as the compiled reference, same
+    count of extension steps as its schedule; also with the short cut switched off."""
+    if name == "repeats" and tau > 2:
+        pytest.skip("no dump")
+    base = common.build_golden_index(workdir, name)
+    ctx = ma.Context.from_files(base, 0)
+    orc = po.Index(base)
+    reads = common.load_reads(name + ".reads.txt")
+    codes, offs = common.encode_reads(reads)
+    ref = po.HitDump.load(os.path.join(common.GOLDEN, "%s.tau%d.bin" % (name, tau)))
+    want_ext = orc.map_batch(codes, offs, tau, threads=2).n_ext
+    for verify in (1, 0):
+        ctx.set_option("verify", verify)
+        b = ctx.upload(codes, offs)
+        c = b.run(tau)
+        h = b.fetch()
+        b.close()
+        assert np.array_equal(h.status, ref.status)
+        assert np.array_equal(h.located(), ref.located())
+        assert h.n_ext == want_ext
+        assert (c["verify_steps"] > 0) == (verify == 1 and len(ref.located()) > 0)
+    ctx.close()
+
+
+def test_verify_at_the_ends_of_the_text_and_at_separators(workdir):
+    """Reads hanging over the first / last sequence's ends, over a separator between sequences, and reads
+    with N, against a text with N runs: windows that leave the text or cross a separator must die exactly
+    where the reference's search does (no child at a separator; src/index_bwt.c:533 sets no bit for it)."""
+    rng = np.random.default_rng(12)
+    seqs = [rng.integers(0, 4, 400).astype(np.uint8) for _ in range(3)]
+    seqs[1][100:130] = 4
+    base = os.path.join(workdir, "edges")
+    ma.HostIndex.build_codes(seqs, ["a", "b", "c"], base).close()
+    ctx = ma.Context.from_files(base, 0)
+    orc = po.Index(base)
+    comp = np.array([3, 2, 1, 0, 4], np.uint8)
+    reads = []
+    for s in seqs:
+        for start in (0, 1, 2, 3, 340, 358, 359, 360):          # 40-letter windows at both ends
+            w = s[start:start + 40].copy()
+            if len(w) < 40:
+                w = np.concatenate([w, rng.integers(0, 4, 40 - len(w)).astype(np.uint8)])   # hangs over the end
+            reads.append(w)
+            reads.append(comp[w[::-1]])
+            v = w.copy(); v[rng.integers(0, 40)] ^= 1            # one substitution
+            reads.append(v)
+            u = w.copy(); u[rng.integers(0, 40)] = 4             # one N
+            reads.append(u)
+    reads.append(np.concatenate([seqs[0][-20:], seqs[1][:20]]))   # across a separator: must not map there
+    reads.append(seqs[1][90:130].copy())                          # into the N run
+    codes = np.concatenate(reads).astype(np.uint8)
+    offs = np.concatenate(([0], np.cumsum([len(r) for r in reads]))).astype(np.int64)
+    for tau in (0, 1, 2, 3):
+        d = orc.map_batch(codes, offs, tau, threads=2)
+        for verify in (1, 0):
+            ctx.set_option("verify", verify)
+            h = ctx.map_batch(codes, offs, tau)
+            assert np.array_equal(h.status, d.status)
+            assert np.array_equal(h.located(), d.located())
+            assert h.n_ext == d.n_ext
+    ctx.close()
+
+
 @pytest.mark.parametrize("jump_k", [0, 4, 9, 14])
 def test_jump_table_changes_nothing(small, jump_k):
     """The K-mer jump table of the leaf phases (k_build_jump) stands in for the first K extension steps:
