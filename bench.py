@@ -189,10 +189,12 @@ def main():
         batch.run(w["tau"])
     barrier()
     t0 = time.perf_counter()
-    ms_search = []
+    ms_search, ms_k_search, ms_k_verify = [], [], []
     for _ in range(args.steps):
         c = batch.run(w["tau"])                      # synchronous: returns when the device work is done
         ms_search.append(c["ms_search"])
+        ms_k_search.append(c["us_k_search"] / 1000.0)
+        ms_k_verify.append(c["us_k_verify"] / 1000.0)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -204,9 +206,13 @@ def main():
     if rank == 0:
         total_reads = w["reads"] * world * args.steps
         value = total_reads / elapsed
-        k_ms = float(np.mean(ms_search))
-        achieved = BYTES_PER_EXT * c["n_ext"] / (k_ms * 1e-3) / 1e9
+        # dominant kernel: k_search.  Its units are the extension steps it executes on the Occ table (the rest of
+        # the reference schedule's steps are served by the jump table and replayed on the text by k_verify).
+        k_ms = float(np.mean(ms_k_search))
+        occ_steps = c["n_ext"] - c["jumped_steps"] - c["verify_steps"]
+        achieved = BYTES_PER_EXT * occ_steps / (k_ms * 1e-3) / 1e9
         traffic, traffic_src = pmc_traffic(args.workload)
+        search_ms = float(np.mean(ms_search))
         out = {
             "metric": "reads mapped/sec (node), 100nt <=2 mm; % HBM gather roofline",
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -217,11 +223,16 @@ def main():
                        "parallelism": "reads sharded over %d GPU(s), index replicated (RCCL broadcast)" % world},
             "roofline": {"bound": "hbm", "kernel": "k_search", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel_ms": k_ms, "ext_steps_per_launch": c["n_ext"],
-                         "algorithmic_bytes_per_launch": BYTES_PER_EXT * c["n_ext"]},
+                         "kernel_ms": k_ms, "ext_steps_per_launch": occ_steps,
+                         "algorithmic_bytes_per_launch": BYTES_PER_EXT * occ_steps,
+                         "k_verify_ms": float(np.mean(ms_k_verify)),
+                         "reference_schedule": {"ext_steps": c["n_ext"], "bytes": BYTES_PER_EXT * c["n_ext"],
+                                                "retired_GBps": BYTES_PER_EXT * c["n_ext"] / (search_ms * 1e-3) / 1e9,
+                                                "note": "SURVEY 8d bytes of the whole reference schedule over k_search + k_verify "
+                                                        "time: a rate of work retired, not a traffic (can exceed the HBM peak)"}},
             "stages_ms": {"search": c["ms_search"], "locate": c["ms_locate"], "order": c["ms_sort"],
                           "total": c["ms_total"]},
-            "hits_per_batch": {"intervals": c["n_hits"], "located": c["n_locs"]},
+            "hits_per_batch": {"list_entries": c["n_hits"], "located": c["n_locs"]},
             "occupancy": {"loop_passes": c["loop_passes"], "continuations": c["continuations"],
                           "steps_from_jump_table": c["jumped_steps"], "steps_replayed_on_text": c["verify_steps"],
                           "steps_on_occ_table": c["n_ext"] - c["jumped_steps"] - c["verify_steps"],

@@ -217,7 +217,8 @@ int           gpumap_batch_counters(const gpumap_batch *batch, int64_t *n_hits, 
 ** (stats[4]).  stats[0] = passes of the search loop summed over all wavefronts (64 nodes each when
 ** full), stats[1] = nodes pushed back as continuations, stats[3] = entries k_search wrote to its
 ** output list (hits and candidates for k_verify), stats[5] = length of that list with the unused ends
-** of the wavefronts' reservations, [6..7] reserved. */
+** of the wavefronts' reservations, stats[6], stats[7] = microseconds of k_search and of k_verify
+** (HIP events on the library's stream; their sum is ms_search). */
 int           gpumap_batch_stats(const gpumap_batch *batch, int64_t stats[8]);
 void          gpumap_batch_free(gpumap_batch *batch);
 

@@ -235,7 +235,7 @@ class Batch:
             raise GpumapError("gpumap_batch_stats failed")
         return dict(n_hits=nh.value, n_locs=nl.value, n_ext=ne.value, ms_search=ms[0], ms_locate=ms[1],
                     ms_sort=ms[2], ms_total=ms[3], loop_passes=st[0], continuations=st[1], jumped_steps=st[2], list_entries=st[3],
-                    verify_steps=st[4], list_length=st[5])
+                    verify_steps=st[4], list_length=st[5], us_k_search=st[6], us_k_verify=st[7])
 
     def fetch(self):
         raw = _Hits()

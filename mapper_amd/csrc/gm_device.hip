@@ -28,7 +28,7 @@ struct gpumap_batch {
    bool have_intervals = false, ran = false;
    int tau = 0;
    float ms[4] = {0, 0, 0, 0};
-   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};      // [4]: between k_search and k_verify
    void release()
    {
       for (DevBuf *b : {&reads, &read_len, &len_row, &phases, &phase_rec, &phase_lo, &status, &hits, &hit_sizes, &hit_off, &keys, &keys_alt,
@@ -564,6 +564,7 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
          hit_cap = (size_t)host_cnt[1] + (size_t)n_waves * HIT_CHUNK;           // pieces are reserved whole, in another order next time
       }
       unsigned long long verify_steps = 0;
+      HIP_TRY(hipEventRecord(b->ev[4], st));
       if (use_verify && host_cnt[1] > 0) {
          VerifyArgs V;
          V.ix = ctx->ix; V.text = (const uint8_t *)ctx->d_text;
@@ -663,6 +664,13 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
       HIP_TRY(hipEventElapsedTime(&b->ms[1], b->ev[1], b->ev[2]));
       HIP_TRY(hipEventElapsedTime(&b->ms[2], b->ev[2], b->ev[3]));
       HIP_TRY(hipEventElapsedTime(&b->ms[3], b->ev[0], b->ev[3]));
+      {
+         float ms_k = 0, ms_v = 0;
+         HIP_TRY(hipEventElapsedTime(&ms_k, b->ev[0], b->ev[4]));
+         HIP_TRY(hipEventElapsedTime(&ms_v, b->ev[4], b->ev[1]));
+         b->stats[6] = (int64_t)(1000.0f * ms_k);
+         b->stats[7] = (int64_t)(1000.0f * ms_v);
+      }
       b->ran = true;
    }
    return 0;

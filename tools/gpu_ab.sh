@@ -11,6 +11,8 @@ for w in $wls; do
   python - $out/bench_$w.json <<'PY'
 import json,sys
 d=json.load(open(sys.argv[1]))
-print(sys.argv[1], "reads/s=%.3g k_ms=%.2f frac=%.3f" % (d["value"], d["roofline"]["kernel_ms"], d["roofline"]["frac"]), d.get("occupancy"), d["stages_ms"])
+r=d["roofline"]; o=d["occupancy"]
+print(sys.argv[1], "reads/s=%.3g k_search=%.2f ms k_verify=%.2f ms frac=%.3f" % (d["value"], r["kernel_ms"], r["k_verify_ms"], r["frac"]),
+      "steps occ/jump/text = %.3g/%.3g/%.3g fill=%.2f" % (o["steps_on_occ_table"], o["steps_from_jump_table"], o["steps_replayed_on_text"], o["lane_fill"] or 0), d["stages_ms"])
 PY
 done
