@@ -571,8 +571,8 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
          V.reads = b->reads.as<const uint8_t>(); V.read_len = b->read_len.as<const uint16_t>();
          V.phase_rec = b->phase_rec.as<const uint2>(); V.phase_lo = b->phase_lo.as<const uint8_t>();
          V.list = b->hits.as<Node>(); V.n_list = (int64_t)host_cnt[1]; V.stride = b->stride; V.n_ext = cnt + 8;
-         const int vbd = b->stride <= 128 ? 256 : 128;                  // 2 * stride bytes of LDS per thread, at most 64 KB
-         hipLaunchKernelGGL(k_verify, dim3((unsigned)cdiv(V.n_list, vbd)), dim3(vbd), (size_t)2 * b->stride * vbd, st, V);
+         const int vbd = 256;                                           // stride bytes of LDS per thread (one word per four letters)
+         hipLaunchKernelGGL(k_verify, dim3((unsigned)cdiv(V.n_list, vbd)), dim3(vbd), (size_t)b->stride * vbd, st, V);
          HIP_TRY(hipGetLastError());
          HIP_TRY(hipMemcpyAsync(host_cnt, cnt, sizeof host_cnt, hipMemcpyDeviceToHost, st));
          HIP_TRY(hipStreamSynchronize(st));

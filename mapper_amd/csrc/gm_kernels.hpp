@@ -263,10 +263,9 @@ struct VerifyArgs {
 // separator), and applies the rules letter by letter only there.
 __global__ void __launch_bounds__(256) k_verify(VerifyArgs A)
 {
-   extern __shared__ uint32_t s_words[];                  // [2][W][blockDim]: query words, then text words
+   extern __shared__ uint32_t s_words[];                  // [W][blockDim]: per word, the bytes where something happens
    const int BD = (int)blockDim.x, tid = (int)threadIdx.x;
-   const int W = A.stride >> 2;
-   uint32_t *sq = s_words + tid, *st = s_words + W * BD + tid;
+   uint32_t *sev = s_words + tid;
    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
    uint32_t steps = 0;
    if (i < A.n_list && (A.list[i].w[5] >> META_CAND)) {
@@ -286,14 +285,15 @@ __global__ void __launch_bounds__(256) k_verify(VerifyArgs A)
       {
          const uint32_t *q32 = reinterpret_cast<const uint32_t *>(A.reads + (size_t)read * A.stride);
          const int nw = (m + 3) >> 2;
-         for (int w = 0; w < nw; w++) sq[w * BD] = q32[w];
+         // per word: non-zero bytes = letters where text and query differ or either is N or a separator
          if (p0 >= 0 && p0 + 4 * nw <= A.ix.n) {
             const uint32_t *t32 = reinterpret_cast<const uint32_t *>(A.text) + (p0 >> 2);   // the text buffer is padded
             const uint32_t sh = (uint32_t)(p0 & 3);
             uint32_t prev = t32[0];
             for (int w = 0; w < nw; w++) {
                const uint32_t next = t32[w + 1];
-               st[w * BD] = __builtin_amdgcn_alignbyte(next, prev, sh);
+               const uint32_t tw = __builtin_amdgcn_alignbyte(next, prev, sh), qw = q32[w];
+               sev[w * BD] = (qw ^ tw) | ((qw | tw) & 0x04040404u);
                prev = next;
             }
          } else {
@@ -303,7 +303,8 @@ __global__ void __launch_bounds__(256) k_verify(VerifyArgs A)
                   const int64_t tp = p0 + 4 * w + k;
                   v |= (uint32_t)((tp < 0 || tp >= A.ix.n) ? SYMS : A.text[tp]) << (8 * k);
                }
-               st[w * BD] = v;
+               const uint32_t qw = q32[w];
+               sev[w * BD] = (qw ^ v) | ((qw | v) & 0x04040404u);
             }
          }
       }
@@ -312,11 +313,10 @@ __global__ void __launch_bounds__(256) k_verify(VerifyArgs A)
          // one phase: positions pos .. end in the phase's direction
          for (;;) {
             const int w = pos >> 2, b = pos & 3;
-            const uint32_t qw = sq[w * BD], tw = st[w * BD];
             const bool last_word = (end >> 2) == w;
             const int hi_b = fw ? (last_word ? (end & 3) : 3) : b, lo_b = fw ? b : (last_word ? (end & 3) : 0);
             const uint32_t mask = (0xffffffffu >> (8 * (3 - hi_b))) & (0xffffffffu << (8 * lo_b));
-            const uint32_t ev = ((qw ^ tw) | ((qw | tw) & 0x04040404u)) & mask;
+            const uint32_t ev = sev[w * BD] & mask;
             if (ev == 0) {                               // plain matches up to the end of the word or of the phase
                steps += (uint32_t)(hi_b - lo_b + 1);
                if (last_word) {
@@ -332,7 +332,10 @@ __global__ void __launch_bounds__(256) k_verify(VerifyArgs A)
             const int skipped = fw ? e - b : b - e;
             steps += (uint32_t)skipped + 1;
             pos += fw ? skipped : -skipped;
-            const int t = (int)((tw >> (8 * e)) & 0xff), qc = (int)((qw >> (8 * e)) & 0xff);
+            // the two letters themselves are read again from memory: this happens a few times per candidate
+            const int64_t tp = p0 + pos;
+            const int t = (tp < 0 || tp >= A.ix.n) ? SYMS : A.text[tp];
+            const int qc = A.reads[(size_t)read * A.stride + pos];
             if (t == SYMS) { alive = false; break; }                 // separator: no child at all
             const bool mis = qc != UNKNOWN && t != qc;                // text N against a base costs one; query N is free
             if (dash) {
