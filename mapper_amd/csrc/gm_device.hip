@@ -429,7 +429,7 @@ static gpumap_batch *batch_upload(gpumap_ctx *ctx, const uint8_t *src, const int
          GM_FAIL_IF(len < 0, "offsets must not decrease.");
          if (len <= MAX_READ) { b->length_seen[len] = true; maxlen = std::max(maxlen, len); }
       }
-      b->stride = (int)((maxlen + 3) & ~(int64_t)3);
+      b->stride = (int)((maxlen + 15) & ~(int64_t)15);      // rows are read as 16-byte units
       int64_t total = offsets[n_reads] - offsets[0];
       GM_FAIL_IF(total > 0 && src == nullptr, "argument 'codes' is NULL.");
       HIP_TRY(b->reads.ensure((size_t)std::max<int64_t>(1, n_reads) * b->stride));
@@ -571,8 +571,14 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
          V.reads = b->reads.as<const uint8_t>(); V.read_len = b->read_len.as<const uint16_t>();
          V.phase_rec = b->phase_rec.as<const uint2>(); V.phase_lo = b->phase_lo.as<const uint8_t>();
          V.list = b->hits.as<Node>(); V.n_list = (int64_t)host_cnt[1]; V.stride = b->stride; V.n_ext = cnt + 8;
-         const int vbd = 256;                                           // stride bytes of LDS per thread (one word per four letters)
-         hipLaunchKernelGGL(k_verify, dim3((unsigned)cdiv(V.n_list, vbd)), dim3(vbd), (size_t)b->stride * vbd, st, V);
+         const int vbd = 256;
+         const dim3 vgrid((unsigned)cdiv(V.n_list, vbd));
+         switch (cdiv(b->stride, 64)) {                                 // 64-letter pieces of the longest read
+            case 1:  hipLaunchKernelGGL(k_verify<1>, vgrid, dim3(vbd), 0, st, V); break;
+            case 2:  hipLaunchKernelGGL(k_verify<2>, vgrid, dim3(vbd), 0, st, V); break;
+            case 3:  hipLaunchKernelGGL(k_verify<3>, vgrid, dim3(vbd), 0, st, V); break;
+            default: hipLaunchKernelGGL(k_verify<4>, vgrid, dim3(vbd), 0, st, V); break;
+         }
          HIP_TRY(hipGetLastError());
          HIP_TRY(hipMemcpyAsync(host_cnt, cnt, sizeof host_cnt, hipMemcpyDeviceToHost, st));
          HIP_TRY(hipStreamSynchronize(st));

@@ -256,16 +256,24 @@ struct VerifyArgs {
    unsigned long long *n_ext;   // [64] partial sums (one hot address would serialise the waves)
 };
 
-// The query row and the text window of a candidate are first copied into LDS as words aligned with
-// each other (all loads of a thread in flight together: one memory round trip instead of one per word
-// walked), word w of thread t at [w * blockDim + t] (every lane its own bank).  The walk then goes a
-// word at a time while nothing happens, jumps to the first letter where something does (mismatch, N,
-// separator), and applies the rules letter by letter only there.
+// The query row and the text window of a candidate are read as 16-byte units (every lane of a load
+// touches a line of its own, so the number of load instructions is what the cache pays for) and
+// compared a word at a time in registers; what is kept is one bit per letter: E = the letter costs a
+// mismatch (text and query differ and the query letter is not N), S = the text holds a separator
+// there.  The walk then goes from event to event with ffs / clz on those bits: plain matches between
+// events are counted, not visited.  NCH = 64-letter pieces of the longest read of the batch.
+__device__ __forceinline__ uint32_t sel4w(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t j)
+{
+   uint32_t r = a;
+   r = j == 1 ? b : r;
+   r = j == 2 ? c : r;
+   r = j == 3 ? d : r;
+   return r;
+}
+
+template <int NCH>
 __global__ void __launch_bounds__(256) k_verify(VerifyArgs A)
 {
-   extern __shared__ uint32_t s_words[];                  // [W][blockDim]: per word, the bytes where something happens
-   const int BD = (int)blockDim.x, tid = (int)threadIdx.x;
-   uint32_t *sev = s_words + tid;
    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
    uint32_t steps = 0;
    if (i < A.n_list && (A.list[i].w[5] >> META_CAND)) {
@@ -282,29 +290,63 @@ __global__ void __launch_bounds__(256) k_verify(VerifyArgs A)
       int score = (meta >> META_SCORE) & 7, sref = (meta >> META_SREF) & 7;
       const int lo = fw ? A.phase_lo[row * MAX_PHASES + phase] : pos + 1;      // lowest query position matched so far
       const int64_t p0 = sa_entry(A.ix.sa, A.ix.sar_bits, fp) - lo;              // text position of query position 0
-      {
-         const uint32_t *q32 = reinterpret_cast<const uint32_t *>(A.reads + (size_t)read * A.stride);
-         const int nw = (m + 3) >> 2;
-         // per word: non-zero bytes = letters where text and query differ or either is N or a separator
-         if (p0 >= 0 && p0 + 4 * nw <= A.ix.n) {
-            const uint32_t *t32 = reinterpret_cast<const uint32_t *>(A.text) + (p0 >> 2);   // the text buffer is padded
-            const uint32_t sh = (uint32_t)(p0 & 3);
-            uint32_t prev = t32[0];
-            for (int w = 0; w < nw; w++) {
-               const uint32_t next = t32[w + 1];
-               const uint32_t tw = __builtin_amdgcn_alignbyte(next, prev, sh), qw = q32[w];
-               sev[w * BD] = (qw ^ tw) | ((qw | tw) & 0x04040404u);
-               prev = next;
-            }
-         } else {
-            for (int w = 0; w < nw; w++) {              // a window over an end of the text: separators outside
-               uint32_t v = 0;
-               for (int k = 0; k < 4; k++) {
-                  const int64_t tp = p0 + 4 * w + k;
-                  v |= (uint32_t)((tp < 0 || tp >= A.ix.n) ? SYMS : A.text[tp]) << (8 * k);
+      uint64_t E[NCH], S[NCH];
+#pragma unroll
+      for (int c = 0; c < NCH; c++) { E[c] = 0; S[c] = 0; }
+      const int nq = (m + 15) >> 4;                                            // 16-letter units of the query row
+      // whole units inside the text buffer (16 bytes of padding behind the text) and the window inside the text
+      bool fast = p0 >= 0 && p0 + m <= A.ix.n && 16 * ((p0 >> 4) + nq + 1) <= A.ix.n + 16;
+      if (fast) {
+         const uint4 *q16 = reinterpret_cast<const uint4 *>(A.reads + (size_t)read * A.stride);
+         const uint4 *t16 = reinterpret_cast<const uint4 *>(A.text) + (p0 >> 4);
+         const uint32_t ws = (uint32_t)(p0 >> 2) & 3, sh = (uint32_t)p0 & 3;
+         uint32_t sepacc = 0;
+         uint4 carry = t16[0];
+#pragma unroll
+         for (int c = 0; c < NCH; c++) {
+            if (4 * c < nq) {
+               uint32_t T[20], Q[16];
+               T[0] = carry.x; T[1] = carry.y; T[2] = carry.z; T[3] = carry.w;
+#pragma unroll
+               for (int j = 0; j < 4; j++) {
+                  uint4 tv = make_uint4(0, 0, 0, 0), qv = make_uint4(0, 0, 0, 0);
+                  if (4 * c + j < nq) { tv = t16[4 * c + j + 1]; qv = q16[4 * c + j]; }
+                  T[4 + 4 * j] = tv.x; T[5 + 4 * j] = tv.y; T[6 + 4 * j] = tv.z; T[7 + 4 * j] = tv.w;
+                  Q[4 * j] = qv.x; Q[4 * j + 1] = qv.y; Q[4 * j + 2] = qv.z; Q[4 * j + 3] = qv.w;
                }
-               const uint32_t qw = q32[w];
-               sev[w * BD] = (qw ^ v) | ((qw | v) & 0x04040404u);
+               carry = make_uint4(T[16], T[17], T[18], T[19]);
+               uint32_t X[17];
+#pragma unroll
+               for (int j = 0; j < 17; j++) X[j] = sel4w(T[j], T[j + 1], T[j + 2], T[j + 3], ws);
+               uint32_t half[2] = {0, 0};
+#pragma unroll
+               for (int w = 0; w < 16; w++) {
+                  const uint32_t tw = __builtin_amdgcn_alignbyte(X[w + 1], X[w], sh), qw = Q[w];
+                  const uint32_t x = qw ^ tw;
+                  const uint32_t d = (x | (x >> 1) | (x >> 2)) & ~(qw >> 2) & 0x01010101u;   // letters that cost a mismatch
+                  sepacc |= (tw >> 2) & tw;                                                  // bit 0 of a byte: code 5
+                  half[w >> 3] |= ((d * 0x01020408u) >> 24) << (4 * (w & 7));                // bits 0,8,16,24 -> 0,1,2,3
+               }
+               E[c] = (uint64_t)half[0] | ((uint64_t)half[1] << 32);
+            }
+         }
+         if (sepacc & 0x01010101u) fast = false;           // a separator in (or just behind) the window
+      }
+      if (!fast) {
+         // a window over an end of the text or over a separator: letter by letter, separators outside the text
+#pragma unroll
+         for (int c = 0; c < NCH; c++) { E[c] = 0; S[c] = 0; }
+         for (int q = 0; q < m; q++) {
+            const int64_t tp = p0 + q;
+            const int t = (tp < 0 || tp >= A.ix.n) ? SYMS : A.text[tp];
+            const int qc = A.reads[(size_t)read * A.stride + q];
+            const uint64_t bit = 1ull << (q & 63);
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+               if ((q >> 6) == c) {
+                  if (t == SYMS) S[c] |= bit;
+                  if (t == SYMS || (qc != UNKNOWN && t != qc)) E[c] |= bit;     // text N against a base costs one; query N is free
+               }
             }
          }
       }
@@ -312,41 +354,38 @@ __global__ void __launch_bounds__(256) k_verify(VerifyArgs A)
       while (alive && !final) {
          // one phase: positions pos .. end in the phase's direction
          for (;;) {
-            const int w = pos >> 2, b = pos & 3;
-            const bool last_word = (end >> 2) == w;
-            const int hi_b = fw ? (last_word ? (end & 3) : 3) : b, lo_b = fw ? b : (last_word ? (end & 3) : 0);
-            const uint32_t mask = (0xffffffffu >> (8 * (3 - hi_b))) & (0xffffffffu << (8 * lo_b));
-            const uint32_t ev = sev[w * BD] & mask;
-            if (ev == 0) {                               // plain matches up to the end of the word or of the phase
-               steps += (uint32_t)(hi_b - lo_b + 1);
-               if (last_word) {
-                  pos = end;
-                  if (!dash && score - sref < diff) alive = false;       // the rule of the phase's last position
-                  break;
+            const int a = fw ? pos : end, b = fw ? end : pos;
+            int first = -1, last = -1;
+            bool sep_first = false, sep_last = false;
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+               const int l = max(a - 64 * c, 0), h = min(b - 64 * c, 63);
+               if (l <= h) {
+                  const uint64_t mk = E[c] & (~0ull << l) & (~0ull >> (63 - h));
+                  if (mk) {
+                     const int f = __ffsll((unsigned long long)mk) - 1, g = 63 - __clzll((long long)mk);
+                     if (first < 0) { first = 64 * c + f; sep_first = (S[c] >> f) & 1; }
+                     last = 64 * c + g; sep_last = (S[c] >> g) & 1;
+                  }
                }
-               pos = fw ? (w + 1) * 4 : w * 4 - 1;
-               continue;
+            }
+            const int e = fw ? first : last;
+            if (e < 0) {                                 // plain matches up to the end of the phase
+               steps += (uint32_t)(b - a + 1);
+               pos = end;
+               if (!dash && score - sref < diff) alive = false;          // the rule of the phase's last position
+               break;
             }
             // plain matches up to the first letter where something happens, then that letter by the rules
-            const int e = fw ? ((__ffs((int)ev) - 1) >> 3) : (3 - (__clz((int)ev) >> 3));
-            const int skipped = fw ? e - b : b - e;
-            steps += (uint32_t)skipped + 1;
-            pos += fw ? skipped : -skipped;
-            // the two letters themselves are read again from memory: this happens a few times per candidate
-            const int64_t tp = p0 + pos;
-            const int t = (tp < 0 || tp >= A.ix.n) ? SYMS : A.text[tp];
-            const int qc = A.reads[(size_t)read * A.stride + pos];
-            if (t == SYMS) { alive = false; break; }                 // separator: no child at all
-            const bool mis = qc != UNKNOWN && t != qc;                // text N against a base costs one; query N is free
-            if (dash) {
-               if (mis) { alive = false; break; }
-            } else {
-               const int s = score + (mis ? 1 : 0);
-               if (s > tau) { alive = false; break; }
-               if (s == tau) { if (s - sref < diff) { alive = false; break; } dash = true; }
-               else if (pos == end && s - sref < diff) { alive = false; break; }
-               score = s;
-            }
+            steps += (uint32_t)(fw ? e - pos : pos - e) + 1;
+            pos = e;
+            if (fw ? sep_first : sep_last) { alive = false; break; }     // separator: no child at all
+            if (dash) { alive = false; break; }
+            const int s = score + 1;
+            if (s > tau) { alive = false; break; }
+            if (s == tau) { if (s - sref < diff) { alive = false; break; } dash = true; }
+            else if (pos == end && s - sref < diff) { alive = false; break; }
+            score = s;
             if (pos == end) break;
             pos += fw ? 1 : -1;
          }
