@@ -84,18 +84,25 @@ int gm_ctx_build_jump(gpumap_ctx *ctx, int k)
 {
    if (ctx->d_jump) { HIP_TRY(hipFree(ctx->d_jump)); ctx->d_jump = nullptr; ctx->jump_k = 0; }
    if (k < 0) {
-      // as many letters as keep the table below 1/16 of an entry per text position, at most 14 (4.3 GB)
+      // as many letters as keep the table at no more than one entry per text position, at most 16 (69 GB),
+      // and the table within a third of the memory that is free
+      size_t free_b = 0, total_b = 0;
+      HIP_TRY(hipMemGetInfo(&free_b, &total_b));
       k = 0;
-      while (k < 14 && ((int64_t)1 << (2 * (k + 1))) <= ctx->ix.n / 16) k++;
+      while (k < 16 && ((int64_t)1 << (2 * (k + 1))) <= ctx->ix.n && ((size_t)16 << (2 * (k + 1))) <= free_b / 3) k++;
       if (k < 4) k = 0;
    }
-   GM_FAIL_IF(k > 14, "jump_k out of range.");
+   GM_FAIL_IF(k > 16, "jump_k out of range.");
    if (k == 0) return 0;
    {
       const int64_t entries = (int64_t)1 << (2 * k);
       HIP_TRY(hipMalloc(&ctx->d_jump, 16 * (size_t)entries));
-      hipLaunchKernelGGL(k_build_jump, dim3((unsigned)cdiv(entries, 256)), dim3(256), 0, ctx->stream, ctx->ix, k, (uint4 *)ctx->d_jump);
-      HIP_TRY(hipGetLastError());
+      const int64_t per_launch = (int64_t)1 << 30;                      // a launch holds fewer than 2^32 threads
+      for (int64_t first = 0; first < entries; first += per_launch) {
+         const int64_t cnt = std::min(per_launch, entries - first);
+         hipLaunchKernelGGL(k_build_jump, dim3((unsigned)cdiv(cnt, 256)), dim3(256), 0, ctx->stream, ctx->ix, k, first, (uint4 *)ctx->d_jump);
+         HIP_TRY(hipGetLastError());
+      }
       HIP_TRY(hipStreamSynchronize(ctx->stream));
       ctx->jump_k = k;
    }

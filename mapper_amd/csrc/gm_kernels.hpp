@@ -134,9 +134,9 @@ __global__ void k_query_all(IndexDev ix, int end, int64_t n, const int64_t *fp, 
 // idx = sum s_t << 2t.  16 bytes in the layout of a node's first four words: fp, rp, sz (40 bits each)
 // and d in the top byte: d = K, or, when sz = 0, the step at which the interval became empty (the
 // reference stops there, after d calls of bwt_query_all).  One thread per K-mer.
-__global__ void k_build_jump(IndexDev ix, int K, uint4 *table)
+__global__ void k_build_jump(IndexDev ix, int K, int64_t first, uint4 *table)
 {
-   const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+   const int64_t idx = first + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
    if (idx >= ((int64_t)1 << (2 * K))) return;
    uint64_t c[SYMS];
    for (int j = 0; j < SYMS; j++) c[j] = ix.tables[TAB_C + j];
