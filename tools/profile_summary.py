@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Condenses the rocprofv3 output of tools/profile_passes.sh into one JSON document:
-kernel-trace stats of our kernels and, per PMC counter, the average per launch of the search kernel."""
+kernel-trace stats of our kernels and, per PMC counter, the average per launch of k_search and of k_verify."""
 import csv, glob, json, os, sys
 
 def main(root):
@@ -14,7 +14,7 @@ def main(root):
     for f in sorted(glob.glob(os.path.join(root, "pmc*", "**", "*counter_collection.csv"), recursive=True)):
         acc = {}
         for r in csv.DictReader(open(f)):
-            if "k_search" not in r["Kernel_Name"]:
+            if "k_search" not in r["Kernel_Name"] and "k_verify" not in r["Kernel_Name"]:
                 continue
             key = (r["Kernel_Name"].split("(")[0], r["Counter_Name"])
             d = acc.setdefault(key, {})
@@ -28,6 +28,7 @@ def main(root):
         try:
             d = json.loads(open(f).read().strip().splitlines()[-1])
             out["bench_lines"][os.path.basename(f)] = {"value": d["value"], "kernel_ms": d["roofline"]["kernel_ms"],
+                                                       "k_verify_ms": d["roofline"].get("k_verify_ms"),
                                                        "ext_steps": d["roofline"]["ext_steps_per_launch"]}
         except Exception as e:  # a pass without a bench line
             out["bench_lines"][os.path.basename(f)] = str(e)
