@@ -186,9 +186,10 @@ typedef struct {
    ** calls of the reference schedule) and device milliseconds of the stages. */
    int64_t   n_ext;
    float     ms_search, ms_locate, ms_sort, ms_total;
-   /* Not NULL: the arrays lie in the context's pinned result arena (option "pinned_results") and stay
-   ** valid until the next gpumap_batch_fetch / gpumap_map_batch on that context; gpumap_hits_free
-   ** then only clears the struct. */
+   /* Not NULL: the arrays lie in the context's pinned result arena (option "pinned_results": two
+   ** arenas used in turn) and stay valid until the second gpumap_batch_fetch / gpumap_map_batch after
+   ** this one on that context, so that one result can be consumed while the next is fetched;
+   ** gpumap_hits_free then only clears the struct. */
    void     *arena;
 } gpumap_hits;
 
@@ -206,6 +207,12 @@ gpumap_batch *gpumap_batch_upload(gpumap_ctx *ctx, const uint8_t *codes, const i
 /* Letters instead of codes: encoded on the device with the index's sym_table. */
 gpumap_batch *gpumap_batch_upload_text(gpumap_ctx *ctx, const char *text, const int64_t *offsets,
                                        int64_t n_reads);
+/* The next chunk into the same batch object (the iteration of mapper()'s loop, src/mapper.c:23-40):
+** the device buffers the batch holds are kept and grow only when the new chunk needs more, so a
+** caller that maps chunk after chunk pays for the allocations once.  Results of the previous chunk
+** that were not fetched are gone. */
+int           gpumap_batch_refill_text(gpumap_ctx *ctx, gpumap_batch *batch, const char *text,
+                                       const int64_t *offsets, int64_t n_reads);
 int           gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *batch, int tau, int want_intervals);
 int           gpumap_batch_fetch(gpumap_ctx *ctx, gpumap_batch *batch, gpumap_hits *out);
 /* Counters of the last run without copying hits: n_hits, n_locs, n_ext, and stage times (ms). */

@@ -79,6 +79,7 @@ API = {
     "gpumap_hits_free": (None, [C.POINTER(_Hits)]),
     "gpumap_batch_upload": (_P, [_P, _P, _P, _I64]),
     "gpumap_batch_upload_text": (_P, [_P, _P, _P, _I64]),
+    "gpumap_batch_refill_text": (_I, [_P, _P, _P, _P, _I64]),
     "gpumap_batch_run": (_I, [_P, _P, _I, _I]),
     "gpumap_batch_fetch": (_I, [_P, _P, C.POINTER(_Hits)]),
     "gpumap_batch_counters": (_I, [_P, C.POINTER(_I64), C.POINTER(_I64), C.POINTER(_I64), C.POINTER(C.c_float)]),

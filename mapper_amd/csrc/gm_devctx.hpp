@@ -85,8 +85,9 @@ struct gpumap_ctx {
    DevBuf spill, counters, op_in, op_out, cub_tmp;
    // option "pinned_results": results are fetched into one page-locked arena owned by the context
    bool pinned_results = false;
-   void *pin_arena = nullptr;
-   size_t pin_cap = 0;
+   void *pin_arena[2] = {nullptr, nullptr};     // page-locked result arenas, used in turn
+   size_t pin_cap[2] = {0, 0};
+   int pin_turn = 0;
 };
 
 

@@ -19,6 +19,7 @@ struct gpumap_batch {
    int stride = 0;
    std::vector<int64_t> offsets;     // host copy (n_reads + 1)
    DevBuf reads, read_len, len_row, phases, phase_rec, phase_lo, status;
+   DevBuf up_src, up_off;            // staging of the upload (kept by a batch that is refilled)
    DevBuf hits, hit_sizes, hit_off, keys, keys_alt, read_cnt, read_first;
    DevBuf loc_read, loc_pos, loc_fwd, loc_seq, loc_seqpos, loc_strand, loc_score;
    DevBuf hkeys, hkeys_alt, hidx, hidx_alt, hit_read, hit_fp, hit_rp, hit_sz, hit_dp, hit_score, hit_align;
@@ -31,7 +32,7 @@ struct gpumap_batch {
    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};      // [4]: between k_search and k_verify
    void release()
    {
-      for (DevBuf *b : {&reads, &read_len, &len_row, &phases, &phase_rec, &phase_lo, &status, &hits, &hit_sizes, &hit_off, &keys, &keys_alt,
+      for (DevBuf *b : {&up_src, &up_off, &reads, &read_len, &len_row, &phases, &phase_rec, &phase_lo, &status, &hits, &hit_sizes, &hit_off, &keys, &keys_alt,
                         &read_cnt, &read_first, &loc_read, &loc_pos, &loc_fwd, &loc_seq, &loc_seqpos, &loc_strand,
                         &loc_score, &hkeys, &hkeys_alt, &hidx, &hidx_alt, &hit_read, &hit_fp, &hit_rp, &hit_sz,
                         &hit_dp, &hit_score, &hit_align})
@@ -75,7 +76,7 @@ extern "C" void gpumap_destroy(gpumap_ctx *ctx)
    if (ctx->d_text && ctx->owns_text) (void)hipFree(ctx->d_text);
    if (ctx->d_sym_table) (void)hipFree(ctx->d_sym_table);
    for (DevBuf *b : {&ctx->spill, &ctx->counters, &ctx->op_in, &ctx->op_out, &ctx->cub_tmp}) b->release();
-   if (ctx->pin_arena) (void)hipHostFree(ctx->pin_arena);
+   for (void *a : ctx->pin_arena) if (a) (void)hipHostFree(a);
    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
    delete ctx;
 }
@@ -416,17 +417,16 @@ extern "C" void gpumap_batch_free(gpumap_batch *b)
    delete b;
 }
 
-static gpumap_batch *batch_upload(gpumap_ctx *ctx, const uint8_t *src, const int64_t *offsets, int64_t n_reads, bool is_text)
+// Fills `b` with a new set of reads; the device buffers `b` already holds are kept and grow only when
+// the new set needs more (a caller that maps chunk after chunk pays for the allocations once).
+static int batch_fill(gpumap_ctx *ctx, gpumap_batch *b, const uint8_t *src, const int64_t *offsets, int64_t n_reads, bool is_text)
 {
-   gpumap_batch *b = nullptr;
-   DevBuf d_src, d_off;
-   GM_FAIL_IF(ctx == nullptr, "argument 'ctx' is NULL.");
    GM_FAIL_IF(n_reads < 0 || offsets == nullptr, "invalid arguments.");
    GM_FAIL_IF(n_reads >= ((int64_t)1 << 31), "too many reads in one batch.");
    HIP_TRY(hipSetDevice(ctx->device));
-   b = new gpumap_batch();
    b->ctx = ctx;
    b->n_reads = n_reads;
+   b->ran = false; b->have_intervals = false;
    b->offsets.assign(offsets, offsets + n_reads + 1);
    memset(b->length_seen, 0, sizeof b->length_seen);
    {
@@ -442,29 +442,49 @@ static gpumap_batch *batch_upload(gpumap_ctx *ctx, const uint8_t *src, const int
       HIP_TRY(b->reads.ensure((size_t)std::max<int64_t>(1, n_reads) * b->stride));
       HIP_TRY(b->read_len.ensure(2 * (size_t)std::max<int64_t>(1, n_reads)));
       HIP_TRY(b->status.ensure(8 * (size_t)std::max<int64_t>(1, n_reads)));
-      for (auto &e : b->ev) HIP_TRY(hipEventCreate(&e));
+      for (auto &e : b->ev) if (!e) HIP_TRY(hipEventCreate(&e));
       if (n_reads > 0) {
-         HIP_TRY(d_src.ensure((size_t)std::max<int64_t>(1, total)));
-         HIP_TRY(d_off.ensure(8 * (size_t)(n_reads + 1)));
-         if (total > 0) HIP_TRY(hipMemcpyAsync(d_src.p, src + offsets[0], (size_t)total, hipMemcpyHostToDevice, ctx->stream));
+         HIP_TRY(b->up_src.ensure((size_t)std::max<int64_t>(1, total)));
+         HIP_TRY(b->up_off.ensure(8 * (size_t)(n_reads + 1)));
+         if (total > 0) HIP_TRY(hipMemcpyAsync(b->up_src.p, src + offsets[0], (size_t)total, hipMemcpyHostToDevice, ctx->stream));
          std::vector<int64_t> rel((size_t)n_reads + 1);
          for (int64_t r = 0; r <= n_reads; r++) rel[r] = offsets[r] - offsets[0];
-         HIP_TRY(hipMemcpyAsync(d_off.p, rel.data(), 8 * (size_t)(n_reads + 1), hipMemcpyHostToDevice, ctx->stream));
+         HIP_TRY(hipMemcpyAsync(b->up_off.p, rel.data(), 8 * (size_t)(n_reads + 1), hipMemcpyHostToDevice, ctx->stream));
          int64_t threads = n_reads * b->stride;
          hipLaunchKernelGGL(k_encode, dim3((unsigned)std::min<int64_t>(cdiv(threads, 256), 1 << 22)), dim3(256), 0, ctx->stream,
-                            d_src.as<const uint8_t>(), d_off.as<const int64_t>(), n_reads, b->stride,
+                            b->up_src.as<const uint8_t>(), b->up_off.as<const int64_t>(), n_reads, b->stride,
                             is_text ? (const uint8_t *)ctx->d_sym_table : (const uint8_t *)nullptr,
                             b->reads.as<uint8_t>(), b->read_len.as<uint16_t>(), (uint8_t *)nullptr);
          HIP_TRY(hipGetLastError());
          HIP_TRY(hipStreamSynchronize(ctx->stream));
       }
    }
-   d_src.release(); d_off.release();
+   return 0;
+failure_return:
+   return -1;
+}
+
+static gpumap_batch *batch_upload(gpumap_ctx *ctx, const uint8_t *src, const int64_t *offsets, int64_t n_reads, bool is_text)
+{
+   gpumap_batch *b = nullptr;
+   GM_FAIL_IF(ctx == nullptr, "argument 'ctx' is NULL.");
+   b = new gpumap_batch();
+   GM_FAIL_IF(batch_fill(ctx, b, src, offsets, n_reads, is_text) != 0, "cannot upload the batch.");
+   b->up_src.release(); b->up_off.release();             // a one-off batch does not keep its staging
    return b;
 failure_return:
-   d_src.release(); d_off.release();
    gpumap_batch_free(b);
    return nullptr;
+}
+
+extern "C" int gpumap_batch_refill_text(gpumap_ctx *ctx, gpumap_batch *b, const char *text, const int64_t *offsets, int64_t n_reads)
+{
+   GM_FAIL_IF(ctx == nullptr, "argument 'ctx' is NULL.");
+   GM_FAIL_IF(b == nullptr, "argument 'batch' is NULL.");
+   GM_FAIL_IF(b->ctx != ctx, "the batch belongs to another context.");
+   return batch_fill(ctx, b, (const uint8_t *)text, offsets, n_reads, true);
+failure_return:
+   return -1;
 }
 
 extern "C" gpumap_batch *gpumap_batch_upload(gpumap_ctx *ctx, const uint8_t *codes, const int64_t *offsets, int64_t n_reads)
@@ -774,14 +794,17 @@ extern "C" int gpumap_batch_fetch(gpumap_ctx *ctx, gpumap_batch *b, gpumap_hits 
       FetchDst d;
       if (ctx->pinned_results) {
          size_t need = 16 * 256 + 8 * (size_t)(2 * R + 1) + 42 * (size_t)L + 80 * (size_t)H;
-         if (need > ctx->pin_cap) {
-            if (ctx->pin_arena) { HIP_TRY(hipHostFree(ctx->pin_arena)); ctx->pin_arena = nullptr; ctx->pin_cap = 0; }
+         // two arenas in turn: what a fetch hands out stays valid until the fetch after the next one
+         const int k = ctx->pin_turn;
+         ctx->pin_turn ^= 1;
+         if (need > ctx->pin_cap[k]) {
+            if (ctx->pin_arena[k]) { HIP_TRY(hipHostFree(ctx->pin_arena[k])); ctx->pin_arena[k] = nullptr; ctx->pin_cap[k] = 0; }
             need += need / 4;
-            HIP_TRY(hipHostMalloc(&ctx->pin_arena, need, hipHostMallocDefault));
-            ctx->pin_cap = need;
+            HIP_TRY(hipHostMalloc(&ctx->pin_arena[k], need, hipHostMallocDefault));
+            ctx->pin_cap[k] = need;
          }
-         d.arena = (char *)ctx->pin_arena;
-         out->arena = ctx->pin_arena;
+         d.arena = (char *)ctx->pin_arena[k];
+         out->arena = ctx->pin_arena[k];
       }
       out->n_reads = R; out->n_locs = L; out->n_hits = H; out->n_ext = b->n_ext;
       out->ms_search = b->ms[0]; out->ms_locate = b->ms[1]; out->ms_sort = b->ms[2]; out->ms_total = b->ms[3];
@@ -830,49 +853,3 @@ failure_return:
    return -1;
 }
 
-// ------------------------------------------------------------------------------------------------
-// mapper() (src/mapper.c:3-47): chunks of reads -> GPU batches -> one line per located hit.
-// ------------------------------------------------------------------------------------------------
-extern "C" int gpumap_mapper(const char *qfile, const gpumap_index *index, gpumap_ctx *ctx, int tau, const char *out_path)
-{
-   gm_read_stream *in = nullptr;
-   FILE *fo = nullptr;
-   gpumap_batch *b = nullptr;
-   gpumap_hits h;
-   memset(&h, 0, sizeof h);
-   GM_FAIL_IF(qfile == nullptr, "argument 'qfile' is NULL.");
-   GM_FAIL_IF(index == nullptr, "argument 'index' is NULL.");
-   GM_FAIL_IF(ctx == nullptr, "argument 'ctx' is NULL.");
-   in = gm_reads_open(qfile);
-   GM_FAIL_IF(in == nullptr, "cannot open the read file.");
-   ctx->pinned_results = true;          // h is consumed before the next fetch
-   fo = (out_path == nullptr || !strcmp(out_path, "-")) ? stdout : fopen(out_path, "w");
-   GM_FAIL_IF(fo == nullptr, "cannot open the output file.");
-   {
-      gm_read_chunk chunk;
-      int64_t n;
-      const gpumap_index_view &v = index->view;
-      while ((n = gm_reads_next(in, (size_t)256 << 20 /* IO_DEFAULT_BUFSIZE, src/io.h:13 */, &chunk)) > 0) {
-         fprintf(stderr, "read: %ld sequences.\n", (long)n);                    // src/mapper.c:30
-         b = gpumap_batch_upload_text(ctx, chunk.text.data(), chunk.offsets.data(), n);
-         GM_FAIL_IF(b == nullptr, "cannot upload the batch.");
-         GM_FAIL_IF(gpumap_batch_run(ctx, b, tau, 0) != 0, "batch failed.");
-         GM_FAIL_IF(gpumap_batch_fetch(ctx, b, &h) != 0, "cannot fetch results.");
-         gpumap_batch_free(b); b = nullptr;
-         for (int64_t t = 0; t < h.n_locs; t++)
-            fprintf(fo, "%s\t%s:%ld:%c\t%d\n", chunk.tags[(size_t)h.loc_read[t]].c_str(), v.seq_name[h.loc_seq[t]],
-                    (long)h.loc_seqpos[t], h.loc_strand[t] ? '-' : '+', (int)h.loc_score[t]);
-         gpumap_hits_free(&h);
-      }
-      GM_FAIL_IF(n < 0, "error while reading the read file.");
-   }
-   if (fo != stdout) fclose(fo);
-   gm_reads_close(in);
-   return 0;
-failure_return:
-   gpumap_batch_free(b);
-   gpumap_hits_free(&h);
-   if (fo && fo != stdout) fclose(fo);
-   gm_reads_close(in);
-   return -1;
-}

@@ -3,6 +3,7 @@
 #include <cerrno>
 #include <cstdint>
 #include <cstdio>
+#include <functional>
 #include <string>
 #include <vector>
 #include "gpumap.h"
@@ -40,14 +41,49 @@ struct gpumap_index {
 // prefix of another sorts first).  gm_sufsort.cpp.
 int gm_suffix_sort(const uint8_t *data, int64_t n, int64_t *sa, int threads);
 
+// Growable byte buffer that does not value-initialise what it grows by (a 256-MB chunk is written by
+// read() right away) and keeps its memory when cleared; optionally page-locked (gpumap_host_alloc).
+struct gm_bytes {
+   char  *p = nullptr;
+   size_t n = 0, cap = 0;
+   bool   pinned = false;
+   gm_bytes() = default;
+   gm_bytes(const gm_bytes &) = delete;
+   gm_bytes &operator=(const gm_bytes &) = delete;
+   ~gm_bytes() { release(); }
+   void release();
+   bool reserve(size_t c);                 // keeps the contents; false when out of memory
+   bool resize(size_t k) { if (!reserve(k)) return false; n = k; return true; }
+   void clear() { n = 0; }
+   char *data() { return p; }
+   const char *data() const { return p; }
+   size_t size() const { return n; }
+   bool empty() const { return n == 0; }
+};
+
 // FASTQ / FASTA / raw reader (gm_reads.cpp).
 struct gm_read_chunk {
-   std::vector<char>        text;     // concatenated read letters
-   std::vector<int64_t>     offsets;  // n+1
-   std::vector<std::string> tags;
+   gm_bytes              raw;      // the block of the file the chunk was cut from (tags point into it)
+   gm_bytes              text;     // concatenated read letters
+   std::vector<int64_t>  offsets;  // n+1
+   std::vector<uint32_t> tag_off, tag_len;   // FASTQ / FASTA: the tag of read i is raw[tag_off[i], +tag_len[i])
+   std::vector<uint64_t> eol;      // scratch: ends of the lines of the block
+   int64_t first_line = 1;         // raw format: the tag of read i is its line number, first_line + i
+   bool    numbered = false;
+   double  t_read = 0, t_parse = 0;   // seconds spent on read() and on parsing for this chunk
+   // The tag of read i (not NUL-terminated); `num` is scratch for numbered tags.
+   const char *tag(size_t i, char num[32], size_t *len) const
+   {
+      if (!numbered) { *len = tag_len[i]; return raw.data() + tag_off[i]; }
+      *len = (size_t)snprintf(num, 32, "%ld", (long)(first_line + (int64_t)i));
+      return num;
+   }
 };
 struct gm_read_stream;
 gm_read_stream *gm_reads_open(const char *path);
 // Returns number of reads (0 at EOF, -1 on error); at most `max_bytes` of input per chunk.
 int64_t gm_reads_next(gm_read_stream *s, size_t max_bytes, gm_read_chunk *chunk);
 void gm_reads_close(gm_read_stream *s);
+// fn(t) for t = 0..threads-1 on as many threads (the caller's among them); returns when all are done.
+void gm_parallel_for(int threads, const std::function<void(int)> &fn);
+int gm_host_threads();     // worker threads of the host stages: GPUMAP_HOST_THREADS, else min(16, cores)

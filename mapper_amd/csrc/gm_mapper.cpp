@@ -1,0 +1,222 @@
+// gm_mapper.cpp -- mapper() (src/mapper.c:3-47): chunks of reads -> GPU batches -> one line per located
+// hit.  The reference's loop (read a chunk, work on it, print, next chunk; src/mapper.c:23-40) as three
+// stages that overlap: a reader thread cuts and parses chunk i+1 (gm_reads.cpp), the calling thread
+// maps chunk i on the GPU through the C-ABI of gpumap.h (one batch object, refilled), a writer thread
+// formats and writes chunk i-1 (txt_pos_to_str's "name:pos:strand", src/index_txt.c:480-511, from the
+// sequence id / position / strand the device computed).  Host code only: no HIP in this file.
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <thread>
+#include "gm_host.hpp"
+
+namespace {
+
+struct Job {
+   gm_read_chunk chunk;
+   int64_t n = 0;
+   gpumap_hits h;
+};
+
+// Bounded hand-over between two stages.  close() wakes everybody; pop() returns nullptr when closed and empty.
+struct Chan {
+   std::mutex m;
+   std::condition_variable cv;
+   std::deque<Job *> q;
+   size_t cap;
+   bool closed = false;
+   explicit Chan(size_t c) : cap(c) {}
+   bool push(Job *j)
+   {
+      std::unique_lock<std::mutex> l(m);
+      cv.wait(l, [&] { return q.size() < cap || closed; });
+      if (closed) return false;
+      q.push_back(j);
+      cv.notify_all();
+      return true;
+   }
+   Job *pop()
+   {
+      std::unique_lock<std::mutex> l(m);
+      cv.wait(l, [&] { return !q.empty() || closed; });
+      if (q.empty()) return nullptr;
+      Job *j = q.front();
+      q.pop_front();
+      cv.notify_all();
+      return j;
+   }
+   void wait_empty()
+   {
+      std::unique_lock<std::mutex> l(m);
+      cv.wait(l, [&] { return q.empty() || closed; });
+   }
+   void close()
+   {
+      std::lock_guard<std::mutex> l(m);
+      closed = true;
+      cv.notify_all();
+   }
+   void drain()
+   {
+      std::lock_guard<std::mutex> l(m);
+      for (Job *j : q) delete j;
+      q.clear();
+   }
+};
+
+inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+inline char *put_num(char *p, int64_t v)
+{
+   char tmp[24];
+   int k = 0;
+   uint64_t u = v < 0 ? (uint64_t)(-v) : (uint64_t)v;
+   if (v < 0) *p++ = '-';
+   do { tmp[k++] = (char)('0' + u % 10); u /= 10; } while (u);
+   while (k) *p++ = tmp[--k];
+   return p;
+}
+
+// "tag \t name:pos:strand \t score \n" for the located hits [lo, hi) of a chunk.
+void format_range(const Job &j, const gpumap_index_view &v, const std::vector<size_t> &name_len, int64_t lo, int64_t hi,
+                  std::vector<char> &out)
+{
+   const gpumap_hits &h = j.h;
+   size_t need = 0;
+   char num[32];
+   for (int64_t t = lo; t < hi; t++) {
+      size_t tl;
+      (void)j.chunk.tag((size_t)h.loc_read[t], num, &tl);
+      need += tl + name_len[(size_t)h.loc_seq[t]] + 32;
+   }
+   out.resize(need);
+   char *p = out.data();
+   for (int64_t t = lo; t < hi; t++) {
+      size_t tl;
+      const char *tag = j.chunk.tag((size_t)h.loc_read[t], num, &tl);
+      memcpy(p, tag, tl); p += tl;
+      *p++ = '\t';
+      const size_t nl = name_len[(size_t)h.loc_seq[t]];
+      memcpy(p, v.seq_name[h.loc_seq[t]], nl); p += nl;
+      *p++ = ':';
+      p = put_num(p, h.loc_seqpos[t]);
+      *p++ = ':';
+      *p++ = h.loc_strand[t] ? '-' : '+';
+      *p++ = '\t';
+      p = put_num(p, (int64_t)h.loc_score[t]);
+      *p++ = '\n';
+   }
+   out.resize((size_t)(p - out.data()));
+}
+
+}  // namespace
+
+extern "C" int gpumap_mapper(const char *qfile, const gpumap_index *index, gpumap_ctx *ctx, int tau, const char *out_path)
+{
+   gm_read_stream *in = nullptr;
+   FILE *fo = nullptr;
+   gpumap_batch *b = nullptr;
+   Chan to_gpu(2), to_writer(1), spare(4);      // spare: chunk objects go round, their buffers are allocated once
+   std::thread reader, writer;
+   int reader_rc = 0, writer_rc = 0;
+   bool failed = false;
+   GM_FAIL_IF(qfile == nullptr, "argument 'qfile' is NULL.");
+   GM_FAIL_IF(index == nullptr, "argument 'index' is NULL.");
+   GM_FAIL_IF(ctx == nullptr, "argument 'ctx' is NULL.");
+   in = gm_reads_open(qfile);
+   GM_FAIL_IF(in == nullptr, "cannot open the read file.");
+   fo = (out_path == nullptr || !strcmp(out_path, "-")) ? stdout : fopen(out_path, "w");
+   GM_FAIL_IF(fo == nullptr, "cannot open the output file.");
+   GM_FAIL_IF(gpumap_set_option(ctx, "pinned_results", 1) != 0, "cannot set up the result buffers.");
+   {
+      const gpumap_index_view &v = index->view;
+      std::vector<size_t> name_len((size_t)v.seq_cnt);
+      for (int64_t i = 0; i < v.seq_cnt; i++) name_len[(size_t)i] = strlen(v.seq_name[i]);
+      size_t chunk_bytes = (size_t)256 << 20;                     // IO_DEFAULT_BUFSIZE, src/io.h:13
+      if (const char *e = getenv("GPUMAP_CHUNK_BYTES")) chunk_bytes = (size_t)std::max<long long>(1, atoll(e));
+      const int T = gm_host_threads();
+      double t_read = 0, t_parse = 0, t_upload = 0, t_run = 0, t_fetch = 0, t_format = 0, t_write = 0, t_wait = 0;
+      const double t_begin = now_s();
+
+      for (int i = 0; i < 4; i++) {
+         Job *j = new Job();
+         j->chunk.text.pinned = true;                             // uploaded from where the parser writes it
+         spare.push(j);
+      }
+      reader = std::thread([&] {
+         for (;;) {
+            Job *j = spare.pop();
+            if (j == nullptr) break;
+            memset(&j->h, 0, sizeof j->h);
+            j->n = gm_reads_next(in, chunk_bytes, &j->chunk);
+            t_read += j->chunk.t_read; t_parse += j->chunk.t_parse;
+            if (j->n <= 0) { reader_rc = j->n < 0 ? -1 : 0; delete j; break; }
+            if (!to_gpu.push(j)) { delete j; break; }
+         }
+         to_gpu.close();
+      });
+      writer = std::thread([&] {
+         std::vector<std::vector<char>> parts((size_t)T);
+         while (Job *j = to_writer.pop()) {
+            const int64_t L = j->h.n_locs;
+            const double w0 = now_s();
+            gm_parallel_for(T, [&](int t) { format_range(*j, v, name_len, L * t / T, L * (t + 1) / T, parts[(size_t)t]); });
+            const double w1 = now_s();
+            for (auto &part : parts)
+               if (!part.empty() && fwrite(part.data(), 1, part.size(), fo) != part.size()) writer_rc = -1;
+            t_format += w1 - w0; t_write += now_s() - w1;
+            gpumap_hits_free(&j->h);
+            if (!spare.push(j)) delete j;
+            if (writer_rc != 0) { to_writer.close(); break; }
+         }
+      });
+
+      while (Job *j = to_gpu.pop()) {
+         fprintf(stderr, "read: %ld sequences.\n", (long)j->n);                 // src/mapper.c:30
+         int rc = 0;
+         const double g0 = now_s();
+         if (b == nullptr) {
+            b = gpumap_batch_upload_text(ctx, j->chunk.text.data(), j->chunk.offsets.data(), j->n);
+            rc = b == nullptr ? -1 : 0;
+         } else {
+            rc = gpumap_batch_refill_text(ctx, b, j->chunk.text.data(), j->chunk.offsets.data(), j->n);
+         }
+         const double g1 = now_s();
+         if (rc == 0) rc = gpumap_batch_run(ctx, b, tau, 0);
+         const double g2 = now_s();
+         // the arena this fetch writes to was handed out two fetches ago: its chunk is written once the
+         // writer has taken the chunk after it
+         if (rc == 0) to_writer.wait_empty();
+         const double g3 = now_s();
+         if (rc == 0) rc = gpumap_batch_fetch(ctx, b, &j->h);
+         t_upload += g1 - g0; t_run += g2 - g1; t_wait += g3 - g2; t_fetch += now_s() - g3;
+         if (rc != 0 || !to_writer.push(j)) { gpumap_hits_free(&j->h); delete j; failed = true; break; }
+      }
+      to_gpu.close();
+      spare.close();
+      reader.join();
+      to_gpu.drain();
+      to_writer.close();       // the writer finishes what it holds: pop() hands out queued jobs before nullptr
+      writer.join();
+      to_writer.drain();
+      spare.drain();
+      if (getenv("GPUMAP_MAPPER_VERBOSE"))
+         fprintf(stderr, "mapper stages (s): reader read %.3f parse %.3f | gpu upload %.3f run %.3f wait-for-writer %.3f fetch %.3f | "
+                 "writer format %.3f write %.3f | wall %.3f\n", t_read, t_parse, t_upload, t_run, t_wait, t_fetch, t_format, t_write,
+                 now_s() - t_begin);
+   }
+   GM_FAIL_IF(failed, "batch failed.");
+   GM_FAIL_IF(reader_rc != 0, "error while reading the read file.");
+   GM_FAIL_IF(writer_rc != 0, "error while writing the output.");
+   gpumap_batch_free(b);
+   if (fo != stdout) fclose(fo); else fflush(fo);
+   gm_reads_close(in);
+   return 0;
+failure_return:
+   gpumap_batch_free(b);
+   if (fo && fo != stdout) fclose(fo);
+   gm_reads_close(in);
+   return -1;
+}

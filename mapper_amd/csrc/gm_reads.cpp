@@ -1,31 +1,86 @@
 // gm_reads.cpp -- chunked read input, behaviour of io_stream_read_seq (src/io.c:113-266) and
-// seqread_parse_fastq / _fasta (src/seqread.c:119-164), without one malloc per line: letters of a
-// chunk go into one flat buffer with offsets, ready for a single upload.
+// seqread_parse_fastq / _fasta (src/seqread.c:119-164) without a getline, two strdup and a malloc
+// per read: a chunk is one block of the file, its lines are found by several threads, letters go
+// into one flat buffer with offsets (ready for a single upload) and tags stay where they are in the
+// block.
 //   first character '@' : FASTQ, 4 lines per read, tag = line 1 without '@', quality length checked
 //                 '>' : FASTA, 2 lines per read (one sequence line, as in the reference)
 //                 else: raw,   1 line per read, tag = its 1-based line number (src/io.c:171-174)
+// A chunk ends at the first record boundary at which the lines read so far hold max_bytes or more
+// (src/io.c:196-198); a line's content stops at a NUL (the reference handles lines as C strings).
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
+#include <thread>
 #include "gm_host.hpp"
 
 struct gm_read_stream {
-   FILE   *fin = nullptr;
+   int     fd = -1;
    int64_t line = 1;          // src/io.c:61
    int     parser_lines = 0;  // 0 = not yet detected
-   bool    eof = false;
-   char   *buf = nullptr;
-   size_t  cap = 0;
+   bool    eof = false;       // the reference's flag: set when a read attempt found the end of the file
+   bool    file_end = false;  // no byte of the file is left unread
+   bool    regular = false;   // a regular file: its size is known and slices can be read side by side
+   int64_t file_size = 0, file_off = 0;
+   gm_bytes carry;            // bytes read from the file that belong to the next chunk
 };
+
+void gm_bytes::release()
+{
+   if (p) { if (pinned) gpumap_host_free(p); else free(p); }
+   p = nullptr; n = cap = 0;
+}
+
+bool gm_bytes::reserve(size_t c)
+{
+   if (c <= cap) return true;
+   c = std::max(c, cap + cap / 2);
+   if (!pinned) {
+      char *q = (char *)realloc(p, c);
+      if (!q) return false;
+      p = q; cap = c;
+      return true;
+   }
+   char *q = (char *)gpumap_host_alloc(c);
+   if (!q) return false;
+   if (n) memcpy(q, p, n);
+   if (p) gpumap_host_free(p);
+   p = q; cap = c;
+   return true;
+}
+
+void gm_parallel_for(int threads, const std::function<void(int)> &fn)
+{
+   if (threads <= 1) { fn(0); return; }
+   std::vector<std::thread> pool;
+   pool.reserve((size_t)threads - 1);
+   for (int t = 1; t < threads; t++) pool.emplace_back(fn, t);
+   fn(0);
+   for (auto &th : pool) th.join();
+}
+
+int gm_host_threads()
+{
+   const char *e = getenv("GPUMAP_HOST_THREADS");
+   int t = e ? atoi(e) : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+   return std::max(1, std::min(t, 64));
+}
 
 gm_read_stream *gm_reads_open(const char *path)
 {
    gm_read_stream *s = nullptr;
-   FILE *f = nullptr;
+   int fd = -1;
+   struct stat sb;
    GM_FAIL_IF(path == nullptr, "argument 'path' is NULL.");
-   f = fopen(path, "r");
-   GM_FAIL_IF(f == nullptr, "cannot open file.");
+   fd = open(path, O_RDONLY);
+   GM_FAIL_IF(fd < 0, "cannot open file.");
    s = new gm_read_stream();
-   s->fin = f;
+   s->fd = fd;
+   if (fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode)) { s->regular = true; s->file_size = (int64_t)sb.st_size; }
    return s;
 failure_return:
    return nullptr;
@@ -34,54 +89,155 @@ failure_return:
 void gm_reads_close(gm_read_stream *s)
 {
    if (!s) return;
-   if (s->fin) fclose(s->fin);
-   free(s->buf);
+   if (s->fd >= 0) close(s->fd);
    delete s;
+}
+
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// Appends file bytes to `raw` until it holds `want` bytes or the file ends.  A regular file is read in
+// slices side by side (the copy out of the page cache is what takes the time).
+static int fill(gm_read_stream *s, gm_bytes &raw, size_t want, int threads)
+{
+   if (raw.size() >= want || s->file_end) return 0;
+   if (!raw.reserve(want)) return -1;
+   if (s->regular) {
+      const size_t have = raw.size();
+      const size_t take = (size_t)std::min<int64_t>((int64_t)(want - have), std::max<int64_t>(0, s->file_size - s->file_off));
+      const int T = take >= ((size_t)8 << 20) ? threads : 1;
+      std::vector<int> bad((size_t)T, 0);
+      gm_parallel_for(T, [&](int t) {
+         size_t a = take * (size_t)t / (size_t)T;
+         const size_t b = take * (size_t)(t + 1) / (size_t)T;
+         while (a < b) {
+            ssize_t got = pread(s->fd, raw.data() + have + a, b - a, (off_t)(s->file_off + (int64_t)a));
+            if (got <= 0) { bad[(size_t)t] = 1; return; }         // the file shrank, or an I/O error
+            a += (size_t)got;
+         }
+      });
+      for (int x : bad) if (x) return -1;
+      raw.n = have + take;
+      s->file_off += (int64_t)take;
+      if (s->file_off >= s->file_size) s->file_end = true;
+      return 0;
+   }
+   while (raw.size() < want && !s->file_end) {
+      ssize_t got = read(s->fd, raw.data() + raw.size(), want - raw.size());
+      if (got < 0) return -1;
+      raw.n += (size_t)got;
+      if (got == 0) s->file_end = true;
+   }
+   return 0;
 }
 
 int64_t gm_reads_next(gm_read_stream *s, size_t max_bytes, gm_read_chunk *chunk)
 {
    GM_FAIL_IF(s == nullptr || chunk == nullptr, "NULL argument.");
-   chunk->text.clear(); chunk->offsets.assign(1, 0); chunk->tags.clear();
+   GM_FAIL_IF(max_bytes > ((size_t)1 << 31), "chunks hold at most 2 GiB.");
+   chunk->raw.clear(); chunk->text.clear(); chunk->offsets.assign(1, 0);
+   chunk->tag_off.clear(); chunk->tag_len.clear(); chunk->first_line = s->line; chunk->numbered = false;
+   chunk->t_read = chunk->t_parse = 0;
    if (s->eof) return 0;                                         // src/io.c:128-130
-   if (s->parser_lines == 0) {                                   // io_stream_set_parser, src/io.c:232-266
-      int c = fgetc(s->fin);
-      s->parser_lines = c == '@' ? 4 : (c == '>' ? 2 : 1);
-      if (c != EOF) ungetc(c, s->fin);
-   }
    {
-      size_t bytes_cnt = 0, lineno = 0, seq_len = 0;
-      std::string tag;
-      ssize_t bytes;
-      while ((bytes = getline(&s->buf, &s->cap, s->fin)) > 0) {
-         if (s->buf[bytes - 1] == '\n') s->buf[--bytes] = 0;
-         size_t len = strlen(s->buf);                             // strdup semantics: stops at a NUL
-         size_t fline = lineno % (size_t)s->parser_lines;
-         if (s->parser_lines == 1) {
-            chunk->tags.push_back(std::to_string(s->line));
-            chunk->text.insert(chunk->text.end(), s->buf, s->buf + len);
-            chunk->offsets.push_back((int64_t)chunk->text.size());
-         } else if (fline == 0) {
-            tag.assign(len > 0 ? s->buf + 1 : s->buf);            // lines[0] + 1
-         } else if (fline == 1) {
-            chunk->text.insert(chunk->text.end(), s->buf, s->buf + len);
-            seq_len = len;
-            if (s->parser_lines == 2) { chunk->tags.push_back(tag); chunk->offsets.push_back((int64_t)chunk->text.size()); }
-         } else if (fline == 3) {
-            GM_FAIL_IF(len != seq_len, "inconsistent length of sequence quality.");   // src/seqread.c:47-49
-            chunk->tags.push_back(tag);
-            chunk->offsets.push_back((int64_t)chunk->text.size());
+      gm_bytes &raw = chunk->raw;
+      const size_t slack = (size_t)1 << 20;
+      const int T = gm_host_threads();
+      const double t0 = now_s();
+      GM_FAIL_IF(!raw.resize(s->carry.size()), "out of memory.");
+      if (s->carry.size()) memcpy(raw.data(), s->carry.data(), s->carry.size());
+      s->carry.clear();
+      GM_FAIL_IF(fill(s, raw, std::max<size_t>(max_bytes, 1) + slack, T) != 0, "error while reading the file.");
+      double t_read = now_s() - t0;
+      if (s->parser_lines == 0)                                   // io_stream_set_parser, src/io.c:232-266
+         s->parser_lines = raw.empty() ? 1 : (raw.data()[0] == '@' ? 4 : (raw.data()[0] == '>' ? 2 : 1));
+      const size_t P = (size_t)s->parser_lines;
+      std::vector<std::vector<uint64_t>> part((size_t)T);
+      std::vector<uint64_t> &eol = chunk->eol;                    // end of every line (one past its '\n', or the end of the file)
+      eol.clear();
+      size_t scanned = 0, n_lines = 0, used = 0;
+      bool at_end = false;                                        // the chunk takes every line the file still has
+      for (;;) {
+         // ends of the lines in raw[scanned, size): slices of the block, one per thread
+         const size_t lo = scanned, hi = raw.size();
+         const char *base = raw.data();
+         gm_parallel_for(hi - lo >= ((size_t)1 << 20) ? T : 1, [&](int t) {
+            const int TT = hi - lo >= ((size_t)1 << 20) ? T : 1;
+            std::vector<uint64_t> &v = part[(size_t)t];
+            v.clear();
+            const size_t a = lo + (hi - lo) * (size_t)t / (size_t)TT, b = lo + (hi - lo) * (size_t)(t + 1) / (size_t)TT;
+            v.reserve((b - a) / 48 + 16);
+            const char *q = base + a, *e = base + b;
+            while (q < e && (q = (const char *)memchr(q, '\n', (size_t)(e - q))) != nullptr) { v.push_back((uint64_t)(q - base) + 1); q++; }
+         });
+         for (auto &v : part) { eol.insert(eol.end(), v.begin(), v.end()); v.clear(); }
+         scanned = hi;
+         // first record boundary with max_bytes or more behind it
+         size_t k = (size_t)(std::lower_bound(eol.begin(), eol.end(), (uint64_t)std::max<size_t>(max_bytes, 1)) - eol.begin());   // lines 0..k hold >= max_bytes
+         size_t need = ((k + 1 + P - 1) / P) * P;
+         if (need <= eol.size()) { n_lines = need; used = (size_t)eol[need - 1]; break; }
+         if (s->file_end) {
+            if (eol.empty() ? !raw.empty() : eol.back() < raw.size()) eol.push_back(raw.size());   // last line without '\n'
+            n_lines = eol.size(); used = raw.size(); at_end = true;
+            break;
          }
-         bytes_cnt += (size_t)bytes;
-         s->line++;
-         lineno++;
-         if (bytes_cnt >= max_bytes && lineno % (size_t)s->parser_lines == 0) break;   // src/io.c:196-198
+         const double r0 = now_s();
+         GM_FAIL_IF(fill(s, raw, raw.size() + std::max(slack, raw.size() / 2), T) != 0, "error while reading the file.");
+         t_read += now_s() - r0;
       }
-      if (bytes == -1) s->eof = true;
-      // an incomplete trailing record is dropped, as the reference never hands it to the parser
-      chunk->text.resize((size_t)chunk->offsets.back());
+      const double t1 = now_s();
+      if (at_end) s->eof = true;                                  // getline returned -1 inside this call
+      GM_FAIL_IF(!s->carry.resize(raw.size() - used), "out of memory.");
+      if (raw.size() > used) memcpy(s->carry.data(), raw.data() + used, raw.size() - used);
+      const size_t n_rec = n_lines / P;                           // an incomplete trailing record is dropped,
+      s->line += (int64_t)n_lines;                                // as the reference never hands it to the parser
+      const char *base = raw.data();
+      auto line_beg = [&](size_t i) { return i == 0 ? (size_t)0 : (size_t)eol[i - 1]; };
+      auto line_len = [&](size_t i) {                             // content: without '\n', up to a NUL
+         size_t b = line_beg(i), e = (size_t)eol[i];
+         if (e > b && base[e - 1] == '\n') e--;
+         const void *z = memchr(base + b, 0, e - b);
+         return z ? (size_t)((const char *)z - (base + b)) : e - b;
+      };
+      const size_t seq_line = P == 1 ? 0 : 1;
+      chunk->offsets.resize(n_rec + 1);
+      chunk->offsets[0] = 0;
+      chunk->numbered = P == 1;
+      if (P != 1) { chunk->tag_off.resize(n_rec); chunk->tag_len.resize(n_rec); }
+      const int TP = n_rec >= 4096 ? T : 1;
+      std::vector<int> bad((size_t)TP, 0);
+      std::vector<int64_t> part_sum((size_t)TP + 1, 0);
+      gm_parallel_for(TP, [&](int t) {
+         const size_t a = n_rec * (size_t)t / (size_t)TP, b = n_rec * (size_t)(t + 1) / (size_t)TP;
+         int64_t sum = 0;
+         for (size_t r = a; r < b; r++) {
+            const size_t len = line_len(P * r + seq_line);
+            sum += (int64_t)len;
+            chunk->offsets[r + 1] = sum;                          // relative to the slice; shifted below
+            if (P != 1) {
+               const size_t tl = line_len(P * r);
+               chunk->tag_off[r] = (uint32_t)(line_beg(P * r) + (tl > 0 ? 1 : 0));       // lines[0] + 1
+               chunk->tag_len[r] = (uint32_t)(tl > 0 ? tl - 1 : 0);
+            }
+            if (P == 4 && line_len(P * r + 3) != len) bad[(size_t)t] = 1;                // src/seqread.c:47-49
+         }
+         part_sum[(size_t)t + 1] = sum;
+      });
+      for (int x : bad) GM_FAIL_IF(x, "inconsistent length of sequence quality.");
+      for (int t = 0; t < TP; t++) part_sum[(size_t)t + 1] += part_sum[(size_t)t];
+      GM_FAIL_IF(!chunk->text.resize((size_t)part_sum[(size_t)TP]), "out of memory.");
+      gm_parallel_for(TP, [&](int t) {
+         const size_t a = n_rec * (size_t)t / (size_t)TP, b = n_rec * (size_t)(t + 1) / (size_t)TP;
+         const int64_t shift = part_sum[(size_t)t];
+         for (size_t r = a; r < b; r++) {
+            const int64_t beg = r == a ? shift : chunk->offsets[r];                // offsets[r] of r > a is shifted already
+            chunk->offsets[r + 1] += shift;
+            memcpy(chunk->text.data() + beg, base + line_beg(P * r + seq_line), (size_t)(chunk->offsets[r + 1] - beg));
+         }
+      });
+      chunk->t_read = t_read;
+      chunk->t_parse = now_s() - t1 + (t1 - t0 - t_read);
+      return (int64_t)n_rec;
    }
-   return (int64_t)chunk->tags.size();
 failure_return:
    return -1;
 }
@@ -97,10 +253,14 @@ extern "C" int64_t gpumap_reads_dump(const char *path, size_t max_bytes, const c
    if (!fo) { gm_reads_close(s); return -1; }
    gm_read_chunk chunk;
    int64_t n, total = 0;
+   char num[32];
    while ((n = gm_reads_next(s, max_bytes, &chunk)) > 0) {
       if (total) fprintf(fo, "#chunk\n");
       for (int64_t i = 0; i < n; i++) {
-         fprintf(fo, "%s\t", chunk.tags[(size_t)i].c_str());
+         size_t tl;
+         const char *tag = chunk.tag((size_t)i, num, &tl);
+         fwrite(tag, 1, tl, fo);
+         fputc('\t', fo);
          fwrite(chunk.text.data() + chunk.offsets[(size_t)i], 1, (size_t)(chunk.offsets[(size_t)i + 1] - chunk.offsets[(size_t)i]), fo);
          fputc('\n', fo);
       }
