@@ -4,6 +4,9 @@
 // maps chunk i on the GPU through the C-ABI of gpumap.h (one batch object, refilled), a writer thread
 // formats and writes chunk i-1 (txt_pos_to_str's "name:pos:strand", src/index_txt.c:480-511, from the
 // sequence id / position / strand the device computed).  Host code only: no HIP in this file.
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <chrono>
 #include <condition_variable>
 #include <cstring>
@@ -111,12 +114,25 @@ void format_range(const Job &j, const gpumap_index_view &v, const std::vector<si
    out.resize((size_t)(p - out.data()));
 }
 
+int write_all(int fd, const char *p, size_t n, int64_t at /* -1: at the file position */)
+{
+   while (n > 0) {
+      ssize_t got = at >= 0 ? pwrite(fd, p, n, (off_t)at) : write(fd, p, n);
+      if (got <= 0) return -1;
+      p += got; n -= (size_t)got;
+      if (at >= 0) at += got;
+   }
+   return 0;
+}
+
 }  // namespace
 
 extern "C" int gpumap_mapper(const char *qfile, const gpumap_index *index, gpumap_ctx *ctx, int tau, const char *out_path)
 {
    gm_read_stream *in = nullptr;
-   FILE *fo = nullptr;
+   int fo = -1;
+   bool fo_regular = false, fo_own = false;
+   int64_t fo_off = 0;
    gpumap_batch *b = nullptr;
    Chan to_gpu(2), to_writer(1), spare(4);      // spare: chunk objects go round, their buffers are allocated once
    std::thread reader, writer;
@@ -127,8 +143,16 @@ extern "C" int gpumap_mapper(const char *qfile, const gpumap_index *index, gpuma
    GM_FAIL_IF(ctx == nullptr, "argument 'ctx' is NULL.");
    in = gm_reads_open(qfile);
    GM_FAIL_IF(in == nullptr, "cannot open the read file.");
-   fo = (out_path == nullptr || !strcmp(out_path, "-")) ? stdout : fopen(out_path, "w");
-   GM_FAIL_IF(fo == nullptr, "cannot open the output file.");
+   if (out_path == nullptr || !strcmp(out_path, "-")) {
+      fflush(stdout);
+      fo = STDOUT_FILENO;
+   } else {
+      fo = open(out_path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
+      GM_FAIL_IF(fo < 0, "cannot open the output file.");
+      fo_own = true;
+      struct stat sb;
+      fo_regular = fstat(fo, &sb) == 0 && S_ISREG(sb.st_mode);       // its parts can be written side by side
+   }
    GM_FAIL_IF(gpumap_set_option(ctx, "pinned_results", 1) != 0, "cannot set up the result buffers.");
    {
       const gpumap_index_view &v = index->view;
@@ -164,8 +188,20 @@ extern "C" int gpumap_mapper(const char *qfile, const gpumap_index *index, gpuma
             const double w0 = now_s();
             gm_parallel_for(T, [&](int t) { format_range(*j, v, name_len, L * t / T, L * (t + 1) / T, parts[(size_t)t]); });
             const double w1 = now_s();
-            for (auto &part : parts)
-               if (!part.empty() && fwrite(part.data(), 1, part.size(), fo) != part.size()) writer_rc = -1;
+            if (fo_regular) {
+               std::vector<int64_t> at((size_t)T + 1, fo_off);
+               for (int t = 0; t < T; t++) at[(size_t)t + 1] = at[(size_t)t] + (int64_t)parts[(size_t)t].size();
+               std::vector<int> bad((size_t)T, 0);
+               gm_parallel_for(T, [&](int t) {
+                  const auto &part = parts[(size_t)t];
+                  if (!part.empty() && write_all(fo, part.data(), part.size(), at[(size_t)t]) != 0) bad[(size_t)t] = 1;
+               });
+               for (int x : bad) if (x) writer_rc = -1;
+               fo_off = at[(size_t)T];
+            } else {
+               for (auto &part : parts)
+                  if (!part.empty() && write_all(fo, part.data(), part.size(), -1) != 0) writer_rc = -1;
+            }
             t_format += w1 - w0; t_write += now_s() - w1;
             gpumap_hits_free(&j->h);
             if (!spare.push(j)) delete j;
@@ -211,12 +247,12 @@ extern "C" int gpumap_mapper(const char *qfile, const gpumap_index *index, gpuma
    GM_FAIL_IF(reader_rc != 0, "error while reading the read file.");
    GM_FAIL_IF(writer_rc != 0, "error while writing the output.");
    gpumap_batch_free(b);
-   if (fo != stdout) fclose(fo); else fflush(fo);
+   if (fo_own) close(fo);
    gm_reads_close(in);
    return 0;
 failure_return:
    gpumap_batch_free(b);
-   if (fo && fo != stdout) fclose(fo);
+   if (fo_own && fo >= 0) close(fo);
    gm_reads_close(in);
    return -1;
 }
