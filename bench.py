@@ -153,7 +153,9 @@ def main():
                 t = torch.as_tensor(_DevPtr(ptr, nbytes), device=torch.device("cuda", local))
             else:
                 t = torch.empty(nbytes, dtype=torch.uint8, device=torch.device("cuda", local))
-            dist.broadcast(t, src=0)
+            piece = 1 << 30                                  # 1-GiB pieces: counts stay far below 2^31 elements
+            for lo in range(0, nbytes, piece):
+                dist.broadcast(t[lo:min(nbytes, lo + piece)], src=0)
             bufs.append(t)
             note("broadcast of buffer %d done (%d bytes)" % (i, nbytes))
         torch.cuda.synchronize()
