@@ -549,7 +549,13 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
       HIP_TRY(hipStreamSynchronize(st));          // the staging vectors above go out of scope
 
       // ---- K2 search (rerun once with an exact buffer if the hit list overflowed)
-      const int wpc = ctx->waves_per_cu ? ctx->waves_per_cu : 12;
+      // persistent waves: as many workgroups as are resident at once (the staged superblock table grows with
+      // the text and can cost a workgroup per CU), unless the option asks for a number
+      const size_t search_lds = (size_t)ctx->ix.n_super * SYMS * 8;
+      int resident_wg = 0;
+      HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident_wg, k_search, WG_THREADS, search_lds));
+      if (getenv("GPUMAP_VERBOSE")) fprintf(stderr, "k_search: %d workgroups of %d waves resident per CU (dynamic LDS %zu B)\n", resident_wg, WG_WAVES, search_lds);
+      const int wpc = ctx->waves_per_cu ? ctx->waves_per_cu : WG_WAVES * std::max(1, std::min(3, resident_wg));
       const int n_wg = std::max(1, ctx->cu_count * wpc / WG_WAVES);
       const int64_t n_waves = (int64_t)n_wg * WG_WAVES;
       HIP_TRY(ctx->spill.ensure((size_t)n_waves * (size_t)ctx->spill_cap * sizeof(Node)));
@@ -580,7 +586,7 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
             A.cursor_chunk = (uint32_t)(rpr * std::min<int64_t>(16, std::max<int64_t>(1, k)));
          }
          if (R > 0) {
-            hipLaunchKernelGGL(k_search, dim3((unsigned)n_wg), dim3(WG_THREADS), (size_t)ctx->ix.n_super * SYMS * 8, st, A);
+            hipLaunchKernelGGL(k_search, dim3((unsigned)n_wg), dim3(WG_THREADS), search_lds, st, A);
             HIP_TRY(hipGetLastError());
          }
          HIP_TRY(hipMemcpyAsync(host_cnt, cnt, 64, hipMemcpyDeviceToHost, st));

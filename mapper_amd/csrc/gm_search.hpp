@@ -19,7 +19,7 @@
 //  * The recursion of the reference (seqsearch_* calling itself, pathstack_t per tree level) is that
 //    deque: pushes compacted with __ballot + popcount prefix, pops hand the newest nodes to idle lanes
 //    (LIFO keeps the frontier small); its oldest part spills to a per-wave global region when full.
-//  * Finished nodes are staged in a per-wave LDS ring; phase records (what a node becomes at the end
+//  * Finished nodes go straight to a piece of the global list reserved by the wave; phase records (what a node becomes at the end
 //    of a phase) and the superblock counts sit in LDS.
 //  * History of the design (a node per quad of lanes, a loop over children, one atomic per emitting
 //    pass: 13 G extension steps/s; this kernel: 44-65 G) is in DESIGN.md section 3.
@@ -29,71 +29,55 @@
 namespace gm {
 
 constexpr int STAGE_SLOT_U4 = 5;     // staging slot per lane, in 16-byte units (4 used + 1 pad)
-constexpr int HITBUF = 64;           // finished nodes staged per wave before they go to the global list
-
-// Finished nodes are staged in a per-wave LDS ring and leave it when the next ones would not fit, into
-// a piece of the global list that the wave has reserved for itself: HIT_CHUNK entries per atomic on
-// the list's counter.  Every atomic on that one address costs all waves about 10 ns (one per emitting
-// pass was the whole kernel time once; one per flush still a third of it).  What a wave leaves unused
-// of its last piece is written as empty entries (sz = 0): the list has holes, its consumers skip them.
+// Finished nodes go straight into a piece of the global list that the wave has reserved for itself:
+// HIT_CHUNK entries per atomic on the list's counter.  Every atomic on that one address costs all
+// waves about 10 ns (one per emitting pass was the whole kernel time once; one per 64 hits still a
+// third of it).  A piece whose rest is too short for the nodes of a pass, and the last piece of a wave,
+// are filled up with empty entries (sz = 0): the list has holes, its consumers skip them.
 constexpr uint32_t HIT_CHUNK = 512;
-struct HitRing {
-   Node *ring;
-   uint32_t head, tail;
+struct HitOut {
    unsigned long long out_base;      // the reserved piece: next free entry, entries left
    uint32_t out_left;
    unsigned long long n_real;        // entries written that are not holes
 };
 
-__device__ __forceinline__ void hit_reserve(const SearchArgs &A, HitRing &hr, int lane)
+__device__ __forceinline__ void hit_holes(const SearchArgs &A, const HitOut &hr, int lane)
 {
-   unsigned long long base = 0;
-   if (lane == 0) base = atomicAdd(A.hit_count, (unsigned long long)HIT_CHUNK);
-   hr.out_base = __shfl(base, 0);
-   hr.out_left = HIT_CHUNK;
-}
-
-__device__ __forceinline__ void hit_flush(const SearchArgs &A, HitRing &hr, int lane, uint32_t n)
-{
-   hr.n_real += n;
-   while (n > 0) {
-      if (hr.out_left == 0) hit_reserve(A, hr, lane);
-      const uint32_t k = min(n, hr.out_left);
-      if ((uint32_t)lane < k && hr.out_base + lane < A.hit_cap) {
-         Node t;
-         lds_load_node<HITBUF>(hr.ring, hr.head + lane, t);
-         uint4 *d = reinterpret_cast<uint4 *>(A.hits + hr.out_base + lane);
-         d[0] = make_uint4(t.w[0], t.w[1], t.w[2], t.w[3]);
-         d[1] = make_uint4(t.w[4], t.w[5], t.w[6], t.w[7]);
-      }
-      hr.head += k; hr.out_base += k; hr.out_left -= k; n -= k;
-   }
-   wave_sync();
-}
-
-// End of the wave: the ring goes out, the rest of the reserved piece becomes holes.
-__device__ __forceinline__ void hit_finish(const SearchArgs &A, HitRing &hr, int lane)
-{
-   if (hr.tail != hr.head) hit_flush(A, hr, lane, hr.tail - hr.head);
    for (uint32_t i = lane; i < hr.out_left; i += 64)
       if (hr.out_base + i < A.hit_cap) {
          uint4 *d = reinterpret_cast<uint4 *>(A.hits + hr.out_base + i);
          d[0] = make_uint4(0, 0, 0, 0);
          d[1] = make_uint4(0, 0, 0, 0);
       }
+}
+
+// End of the wave: the rest of the reserved piece becomes holes.
+__device__ __forceinline__ void hit_finish(const SearchArgs &A, HitOut &hr, int lane)
+{
+   hit_holes(A, hr, lane);
    if (lane == 0 && hr.n_real) atomicAdd(A.stats + 3, hr.n_real);
 }
 
 // Converged call: lanes with `flag` append `nd`.
-__device__ __forceinline__ void hit_emit(const SearchArgs &A, HitRing &hr, bool flag, const Node &nd, int lane)
+__device__ __forceinline__ void hit_emit(const SearchArgs &A, HitOut &hr, bool flag, const Node &nd, int lane)
 {
-   unsigned long long m = __ballot(flag);
+   const unsigned long long m = __ballot(flag);
    if (m == 0) return;
    const uint32_t add = (uint32_t)__popcll(m);
-   if (hr.tail - hr.head + add > HITBUF) hit_flush(A, hr, lane, hr.tail - hr.head);
-   if (flag) lds_store_node<HITBUF>(hr.ring, hr.tail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), nd);
-   hr.tail += add;
-   wave_sync();
+   if (hr.out_left < add) {
+      hit_holes(A, hr, lane);
+      unsigned long long base = 0;
+      if (lane == 0) base = atomicAdd(A.hit_count, (unsigned long long)HIT_CHUNK);
+      hr.out_base = __shfl(base, 0);
+      hr.out_left = HIT_CHUNK;
+   }
+   const unsigned long long at = hr.out_base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
+   if (flag && at < A.hit_cap) {          // beyond the list: counted, not stored (the host runs again with a longer list)
+      uint4 *d = reinterpret_cast<uint4 *>(A.hits + at);
+      d[0] = make_uint4(nd.w[0], nd.w[1], nd.w[2], nd.w[3]);
+      d[1] = make_uint4(nd.w[4], nd.w[5], nd.w[6], nd.w[7]);
+   }
+   hr.out_base += add; hr.out_left -= add; hr.n_real += add;
 }
 
 // Lanes whose quad's lane I is set in `m`: the execution mask of fetch slot I (scalar work only).
@@ -156,7 +140,6 @@ __global__ void __launch_bounds__(WG_THREADS) k_search(SearchArgs A)
 {
    __shared__ Node s_q[WG_WAVES][QCAP];
    __shared__ uint4 s_stage[WG_WAVES][64 * STAGE_SLOT_U4];
-   __shared__ Node s_hit[WG_WAVES][HITBUF];
    __shared__ uint2 s_ph[PH_LDS_ROWS * MAX_PHASES];
    extern __shared__ unsigned long long s_cb[];              // C[j] + count of j before superblock s
 
@@ -176,9 +159,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_search(SearchArgs A)
    uint4 *stage = s_stage[wid];
    uint4 *stage_w = stage + (lane & ~3) * STAGE_SLOT_U4 + sub;      // where this lane writes slot 0 of its quad
    const uint4 *stage_r = stage + lane * STAGE_SLOT_U4;             // this lane's own block
-   HitRing hr;
-   hr.ring = s_hit[wid];
-   hr.head = hr.tail = 0;
+   HitOut hr;
    hr.out_base = 0; hr.out_left = 0; hr.n_real = 0;
    unsigned long long n_iter = 0, n_cont = 0;
    unsigned long long res_base = 0;      // reads reserved from the global cursor (A.cursor_chunk per atomic)
