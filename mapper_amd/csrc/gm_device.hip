@@ -555,7 +555,12 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
       int resident_wg = 0;
       HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident_wg, k_search, WG_THREADS, search_lds));
       if (getenv("GPUMAP_VERBOSE")) fprintf(stderr, "k_search: %d workgroups of %d waves resident per CU (dynamic LDS %zu B)\n", resident_wg, WG_WAVES, search_lds);
-      const int wpc = ctx->waves_per_cu ? ctx->waves_per_cu : WG_WAVES * std::max(1, std::min(3, resident_wg));
+      // 16 waves per CU where four workgroups fit (texts below 2.2 G symbols: the table is small) and the batch
+      // is large enough (small batches start and drain faster with 12).  At GRCh38 size 12 and 16 waves run
+      // alike: the kernel is bound by the rate of random line requests there, not by latency.
+      const int64_t refills = R * (tau + 1) / 64;
+      const int want_wg = refills >= (int64_t)16 * ctx->cu_count * 16 ? 4 : 3;
+      const int wpc = ctx->waves_per_cu ? ctx->waves_per_cu : WG_WAVES * std::max(1, std::min(want_wg, resident_wg));
       const int n_wg = std::max(1, ctx->cu_count * wpc / WG_WAVES);
       const int64_t n_waves = (int64_t)n_wg * WG_WAVES;
       HIP_TRY(ctx->spill.ensure((size_t)n_waves * (size_t)ctx->spill_cap * sizeof(Node)));
