@@ -141,6 +141,93 @@ def test_read_pipeline_matches_reference_io_tests(workdir):
     assert ma.lib().gpumap_reads_dump(b"/nonexistent", 10, b"/tmp/x") == -1
 
 
+def _reference_reader_model(data, max_bytes):
+    """io_stream_read_seq (src/io.c:113-227) + seqread_parse_* (src/seqread.c:14-164) line by line: getline,
+    C-string content (stops at a NUL), chunk ends at the first record boundary with max_bytes behind it.
+    Returns the chunks as lists of (tag, letters), or None where the reference fails (quality length)."""
+    lines, pos = [], 0
+    while pos < len(data):
+        e = data.find(b"\n", pos)
+        e = len(data) if e < 0 else e + 1
+        lines.append(data[pos:e])
+        pos = e
+    P = 4 if data[:1] == b"@" else (2 if data[:1] == b">" else 1)
+
+    def content(b):
+        b = b[:-1] if b.endswith(b"\n") else b
+        z = b.find(b"\0")
+        return b if z < 0 else b[:z]
+    chunks, i, lineno = [], 0, 1
+    while True:
+        cur, cnt, k, tag, seq = [], 0, 0, b"", b""
+        while i < len(lines):
+            c = content(lines[i])
+            f = k % P
+            if P == 1:
+                cur.append((str(lineno).encode(), c))
+            elif f == 0:
+                tag = c[1:] if len(c) > 0 else c
+            elif f == 1:
+                seq = c
+                if P == 2:
+                    cur.append((tag, seq))
+            elif f == 3:
+                if len(c) != len(seq):
+                    return None
+                cur.append((tag, seq))
+            cnt += len(lines[i]); i += 1; k += 1; lineno += 1
+            if cnt >= max_bytes and k % P == 0:
+                break
+        if not cur:
+            return chunks
+        chunks.append(cur)
+        if i >= len(lines) and not (cnt >= max_bytes and k % P == 0):
+            return chunks
+
+
+@pytest.mark.parametrize("threads", ["1", "3", "16"])
+def test_block_reader_against_line_by_line_model(workdir, threads, monkeypatch):
+    """Random files (ragged lines, empty lines, NULs, CRs, no newline at the end, truncated last record) cut
+    at random chunk sizes: the block reader with its threads gives what the reference's getline loop gives."""
+    monkeypatch.setenv("GPUMAP_HOST_THREADS", threads)
+    rng = np.random.default_rng(int(threads))
+    alphabet = np.frombuffer(b"ACGTNacgtn\r\0xy", dtype=np.uint8)
+
+    def rnd_line(lo, hi):
+        return alphabet[rng.integers(0, len(alphabet), int(rng.integers(lo, hi)))].tobytes()
+    for case in range(63):
+        fmt = ("fastq", "fasta", "raw")[case % 3]
+        recs = []
+        big = case >= 60                                  # large enough for the slices of every thread to hold lines
+        for r in range(40000 if big else int(rng.integers(0, 400))):
+            s = rnd_line(0, 120)
+            if fmt == "fastq":
+                q = b"I" * len(s.split(b"\0")[0])
+                recs += [b"@t%d x" % r, s, b"+", q]
+            elif fmt == "fasta":
+                recs += [b">t%d" % r, s]
+            else:
+                recs += [s if not s.startswith((b"@", b">")) or r else b"A" + s]
+        if fmt == "raw" and recs and recs[0][:1] in (b"@", b">"):
+            recs[0] = b"A" + recs[0]
+        if recs and rng.random() < 0.3:
+            recs = recs[:len(recs) - int(rng.integers(0, 3))]          # last record incomplete
+        data = b"\n".join(recs) + (b"\n" if recs and rng.random() < 0.7 else b"")
+        path = os.path.join(workdir, "rnd_reader_%s_%d" % (threads, case))
+        open(path, "wb").write(data)
+        for max_bytes in ((1 << 20, 3_000_000, 1 << 24) if big else
+                          (1, int(rng.integers(2, 300)), int(rng.integers(300, 5000)), 1 << 22)):
+            want = _reference_reader_model(data, max_bytes)
+            n = ma.lib().gpumap_reads_dump(path.encode(), max_bytes, (path + ".dump").encode())
+            if want is None:
+                assert n == -1
+                continue
+            got = open(path + ".dump", "rb").read()
+            exp = b"#chunk\n".join(b"".join(t + b"\t" + q + b"\n" for t, q in c) for c in want)
+            assert n == sum(len(c) for c in want), (case, fmt, max_bytes)
+            assert got == exp, (case, fmt, max_bytes)
+
+
 # ---------------------------------------------------------------- shared kernel core on the host
 
 @pytest.fixture(scope="module")
