@@ -159,18 +159,16 @@ struct NodeR {      // unpacked, in registers
    uint32_t read;
    uint64_t mm;     // mismatch positions + (m-1) << 56
    int pos, end, phase, score, sref, tau, diff;
-   int first = 0;   // first candidate symbol still to be followed (continuations of k_search_lane)
+   int first = 0;   // first candidate symbol still to be followed (continuations of k_search)
    bool dash, fw;
 };
 
 constexpr int META_DASH = 6, META_SCORE = 7, META_SREF = 10, META_FW = 13, META_END = 14, META_TAU = 22,
               META_DIFF = 25, META_FIRST = 28;
 // Entries of the output list of k_search: a finished hit (an interval of the whole read), or, bit 31 set,
-// a node whose interval holds one suffix and that k_verify finishes against the text.  k_verify turns
-// it into a located hit (first = LOCATED: the fp field holds the text position of the read) or
-// empties it (sz = 0).
+// a node whose interval holds one suffix and that k_verify finishes against the text (the list entry
+// stays as it is; what becomes of it goes to the locate stage as a sort key).
 constexpr int META_CAND = 31;
-constexpr uint32_t LOCATED = 7;
 
 constexpr int PHASE_FINAL = 63;
 

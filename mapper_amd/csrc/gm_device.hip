@@ -20,7 +20,7 @@ struct gpumap_batch {
    std::vector<int64_t> offsets;     // host copy (n_reads + 1)
    DevBuf reads, read_len, len_row, phases, phase_rec, phase_lo, status;
    DevBuf up_src, up_off;            // staging of the upload (kept by a batch that is refilled)
-   DevBuf hits, hit_sizes, hit_off, keys, keys_alt, read_cnt, read_first;
+   DevBuf hits, hit_sizes, hit_off, direct, longer, keys, keys_alt, read_cnt, read_first;
    DevBuf loc_read, loc_pos, loc_fwd, loc_seq, loc_seqpos, loc_strand, loc_score;
    DevBuf hkeys, hkeys_alt, hidx, hidx_alt, hit_read, hit_fp, hit_rp, hit_sz, hit_dp, hit_score, hit_align;
    bool length_seen[MAX_READ + 1];
@@ -32,7 +32,7 @@ struct gpumap_batch {
    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};      // [4]: between k_search and k_verify
    void release()
    {
-      for (DevBuf *b : {&up_src, &up_off, &reads, &read_len, &len_row, &phases, &phase_rec, &phase_lo, &status, &hits, &hit_sizes, &hit_off, &keys, &keys_alt,
+      for (DevBuf *b : {&up_src, &up_off, &reads, &read_len, &len_row, &phases, &phase_rec, &phase_lo, &status, &hits, &hit_sizes, &hit_off, &direct, &longer, &keys, &keys_alt,
                         &read_cnt, &read_first, &loc_read, &loc_pos, &loc_fwd, &loc_seq, &loc_seqpos, &loc_strand,
                         &loc_score, &hkeys, &hkeys_alt, &hidx, &hidx_alt, &hit_read, &hit_fp, &hit_rp, &hit_sz,
                         &hit_dp, &hit_score, &hit_align})
@@ -55,7 +55,7 @@ int gm_ctx_common_init(gpumap_ctx *ctx, int device)
    HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
    HIP_TRY(hipMalloc((void **)&ctx->d_sym_table, 256));
    HIP_TRY(hipMemcpy(ctx->d_sym_table, ctx->sym_table, 256, hipMemcpyHostToDevice));
-   HIP_TRY(ctx->counters.ensure(8 * (8 + 64)));      // 8 counters + 64 partial sums of k_verify
+   HIP_TRY(ctx->counters.ensure(8 * (8 + 64 + 1)));      // 8 counters + 64 partial sums of k_verify + the count of long intervals (k_place)
    return 0;
 failure_return:
    return -1;
@@ -602,13 +602,24 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
          hit_cap = (size_t)host_cnt[1] + (size_t)n_waves * HIT_CHUNK;           // pieces are reserved whole, in another order next time
       }
       unsigned long long verify_steps = 0;
+      const int pos_bits = ctx->ix.sar_bits;
+      const int read_bits = bits_for((uint64_t)std::max<int64_t>(R, 1));
+      GM_FAIL_IF(pos_bits + 4 + read_bits > 64, "batch too large for the 64-bit sort key (split the batch).");
       HIP_TRY(hipEventRecord(b->ev[4], st));
-      if (use_verify && host_cnt[1] > 0) {
+      const bool verified = use_verify && host_cnt[1] > 0;
+      if (verified) {
+         const int64_t H = (int64_t)host_cnt[1];
+         GM_FAIL_IF(H >= ((int64_t)1 << 31), "too many entries in the hit list (split the batch).");
+         HIP_TRY(b->hit_sizes.ensure(8 * (size_t)(H + 1)));
+         HIP_TRY(b->direct.ensure(8 * (size_t)H));
+         HIP_TRY(hipMemsetAsync(b->hit_sizes.as<int64_t>() + H, 0, 8, st));
          VerifyArgs V;
          V.ix = ctx->ix; V.text = (const uint8_t *)ctx->d_text;
          V.reads = b->reads.as<const uint8_t>(); V.read_len = b->read_len.as<const uint16_t>();
          V.phase_rec = b->phase_rec.as<const uint2>(); V.phase_lo = b->phase_lo.as<const uint8_t>();
-         V.list = b->hits.as<Node>(); V.n_list = (int64_t)host_cnt[1]; V.stride = b->stride; V.n_ext = cnt + 8;
+         V.list = b->hits.as<const Node>(); V.n_list = H; V.stride = b->stride; V.n_ext = cnt + 8;
+         V.direct = b->direct.as<unsigned long long>(); V.sizes = b->hit_sizes.as<int64_t>();
+         V.key_shift = pos_bits + 4;
          const int vbd = 256;
          const dim3 vgrid((unsigned)cdiv(V.n_list, vbd));
          switch (cdiv(b->stride, 64)) {                                 // 64-letter pieces of the longest read
@@ -630,16 +641,19 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
       b->stats[4] = (int64_t)verify_steps;
       b->stats[5] = (int64_t)host_cnt[1];
 
-      // ---- K3 locate: sizes -> scan -> flat gather
+      // ---- K3 locate: slots per entry -> scan -> every entry fills its slots
       const int64_t H = b->n_hits;
       int64_t L = 0;
       HIP_TRY(b->read_first.ensure(8 * (size_t)(R + 1)));
       if (H > 0) {
+         GM_FAIL_IF(H >= ((int64_t)1 << 31), "too many entries in the hit list (split the batch).");
          HIP_TRY(b->hit_sizes.ensure(8 * (size_t)(H + 1)));
          HIP_TRY(b->hit_off.ensure(8 * (size_t)(H + 1)));
-         HIP_TRY(hipMemsetAsync(b->hit_sizes.p, 0, 8 * (size_t)(H + 1), st));
-         hipLaunchKernelGGL(k_hit_sizes, dim3((unsigned)cdiv(H, 256)), dim3(256), 0, st, b->hits.as<const Node>(), H,
-                            b->hit_sizes.as<int64_t>());
+         if (!verified) {                           // (k_verify has written the sizes)
+            HIP_TRY(hipMemsetAsync(b->hit_sizes.p, 0, 8 * (size_t)(H + 1), st));
+            hipLaunchKernelGGL(k_hit_sizes, dim3((unsigned)cdiv(H, 256)), dim3(256), 0, st, b->hits.as<const Node>(), H,
+                               b->hit_sizes.as<int64_t>());
+         }
          size_t tmp = 0;
          HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, b->hit_sizes.as<int64_t>(), b->hit_off.as<int64_t>(), (int)(H + 1), st));
          HIP_TRY(ctx->cub_tmp.ensure(tmp));
@@ -648,15 +662,21 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
          HIP_TRY(hipStreamSynchronize(st));
       }
       b->n_locs = L;
-      const int pos_bits = ctx->ix.sar_bits;
-      const int read_bits = bits_for((uint64_t)std::max<int64_t>(R, 1));
-      GM_FAIL_IF(pos_bits + 4 + read_bits > 64, "batch too large for the 64-bit sort key (split the batch).");
       if (L > 0) {
          GM_FAIL_IF(L >= ((int64_t)1 << 31), "too many located hits in one batch (split the batch).");
          HIP_TRY(b->keys.ensure(8 * (size_t)L));
          HIP_TRY(b->keys_alt.ensure(8 * (size_t)L));
-         hipLaunchKernelGGL(k_expand_hits, dim3((unsigned)cdiv(L, 256)), dim3(256), 0, st, ctx->ix, b->hits.as<const Node>(), H,
-                            b->hit_off.as<const int64_t>(), L, pos_bits, b->keys.as<unsigned long long>());
+         const unsigned int longer_cap = (unsigned int)(L / PLACE_INLINE + 1);
+         HIP_TRY(b->longer.ensure(4 * (size_t)longer_cap));
+         unsigned int *n_longer = (unsigned int *)(cnt + 8 + 64);
+         HIP_TRY(hipMemsetAsync(n_longer, 0, 8, st));
+         hipLaunchKernelGGL(k_place, dim3((unsigned)cdiv(H, 256)), dim3(256), 0, st, ctx->ix, b->hits.as<const Node>(), H,
+                            verified ? b->direct.as<const unsigned long long>() : (const unsigned long long *)nullptr,
+                            b->hit_sizes.as<const int64_t>(), b->hit_off.as<const int64_t>(), pos_bits, b->keys.as<unsigned long long>(),
+                            b->longer.as<unsigned int>(), n_longer, longer_cap);
+         hipLaunchKernelGGL(k_place_long, dim3((unsigned)(4 * ctx->cu_count)), dim3(256), 0, st, ctx->ix, b->hits.as<const Node>(),
+                            b->hit_sizes.as<const int64_t>(), b->hit_off.as<const int64_t>(), pos_bits, b->keys.as<unsigned long long>(),
+                            b->longer.as<const unsigned int>(), (const unsigned int *)n_longer);
          HIP_TRY(hipGetLastError());
       }
       HIP_TRY(hipEventRecord(b->ev[2], st));

@@ -2,7 +2,7 @@
 //
 //   k_super_counts, k_pack_blocks   K0  reference Occ layout -> 64-byte rank blocks (one-off)
 //   k_search                        K2  block search for a batch of reads (the hot kernel)
-//   k_expand_hits                   K3  suffix-array locate as a flat, balanced gather
+//   k_place, k_place_long           K3  every entry of the hit list fills its slots of the located output
 //   k_encode                        K4  letters -> codes, fixed-stride read matrix
 //   k_occ_all, k_query_all, k_sar_get   batched forms of the reference's single-query operators
 //
@@ -241,7 +241,9 @@ struct SearchArgs {
 // at a separator), so the walk is replayed on the text itself -- same rules, same hits, and the same
 // count of bwt_query_all calls (one per position visited, the one at which the path dies included).
 // One suffix-array entry and a window of the text replace one Occ line per letter.
-// One thread per entry of the output list of k_search; entries that are not candidates are left alone.
+// One thread per entry of the output list of k_search.  A candidate that becomes a hit is finished here:
+// its sort key goes to direct[] (one suffix: its text position is known) and the locate stage only has
+// to move it to its slot; every entry gets its number of slots for the scan of the locate stage.
 // ------------------------------------------------------------------------------------------------
 struct VerifyArgs {
    IndexDev ix;
@@ -250,10 +252,13 @@ struct VerifyArgs {
    const uint16_t *read_len;
    const uint2    *phase_rec;   // [rows][MAX_PHASES]
    const uint8_t  *phase_lo;    // [rows][MAX_PHASES]
-   Node *list;
+   const Node *list;
    int64_t n_list;
    int stride;
-   unsigned long long *n_ext;   // [64] partial sums (one hot address would serialise the waves)
+   unsigned long long *n_ext;      // [64] partial sums (one hot address would serialise the waves)
+   unsigned long long *direct;     // [n_list] sort key of the hit a candidate became, ~0 for every other entry
+   int64_t *sizes;                 // [n_list] slots of the entry in the located output: 1 for such a hit, the suffixes of an interval
+   int key_shift;                  // key = read << key_shift | text position << 4 | score (as k_place)
 };
 
 // The query row and the text window of a candidate are read as 16-byte units (every lane of a load
@@ -276,6 +281,12 @@ __global__ void __launch_bounds__(256) k_verify(VerifyArgs A)
 {
    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
    uint32_t steps = 0;
+   unsigned long long key = ~0ull;
+   if (i < A.n_list && !(A.list[i].w[5] >> META_CAND)) {
+      const Node &e = A.list[i];
+      A.sizes[i] = (int64_t)e.w[2] | ((int64_t)((e.w[3] >> 16) & 0xff) << 32);
+      A.direct[i] = key;
+   }
    if (i < A.n_list && (A.list[i].w[5] >> META_CAND)) {
       Node nd = A.list[i];
       const int64_t fp = (int64_t)nd.w[0] | ((int64_t)(nd.w[3] & 0xff) << 32);
@@ -398,15 +409,10 @@ __global__ void __launch_bounds__(256) k_verify(VerifyArgs A)
          sref = score;
          pos = (int)(rec.y & 255);
       }
-      // located hit: the text position of the read's first letter in the fp field, one suffix; or nothing
-      const int64_t where = final ? p0 : 0;
-      nd.w[0] = (uint32_t)where;
-      nd.w[2] = final ? 1u : 0u;
-      nd.w[3] = (uint32_t)((where >> 32) & 0xff);
-      nd.w[5] = (uint32_t)phase | ((uint32_t)score << META_SCORE) | (LOCATED << META_FIRST);
-      uint4 *d = reinterpret_cast<uint4 *>(A.list + i);
-      d[0] = make_uint4(nd.w[0], nd.w[1], nd.w[2], nd.w[3]);
-      d[1] = make_uint4(nd.w[4], nd.w[5], nd.w[6], nd.w[7]);
+      // a hit: the text position of the read's first letter, one suffix; or nothing
+      if (final) key = ((unsigned long long)read << A.key_shift) | ((unsigned long long)p0 << 4) | (unsigned long long)score;
+      A.direct[i] = key;
+      A.sizes[i] = final ? 1 : 0;
    }
    for (int o = 32; o > 0; o >>= 1) steps += (uint32_t)__shfl_xor((int)steps, o);
    if ((threadIdx.x & 63) == 0 && steps) atomicAdd(A.n_ext + (blockIdx.x & 63), (unsigned long long)steps);
@@ -486,12 +492,15 @@ __device__ __forceinline__ void wave_push(WaveQueue &wq, bool flag, const Node &
 // (k_search itself is in gm_search.hpp.)
 
 // ------------------------------------------------------------------------------------------------
-// K3: locate.  hit_off = exclusive scan of the hit sizes.  Output slot t belongs to the hit h with
-// hit_off[h] <= t < hit_off[h+1]; consecutive slots of one hit read consecutive packed SA entries
-// (sar_get_range, src/index_sar.c:121-161), so a wave reads a contiguous bit range.
+// K3: locate.  hit_off = exclusive scan of the slots per entry of the list.  One thread per entry: a hit
+// k_verify finished brings its key; an interval reads its suffix-array entries (sar_get_range,
+// src/index_sar.c:121-161), up to PLACE_INLINE of them here, longer ones go to a list that k_place_long
+// works through a workgroup per interval.
 // key = read << (pos_bits + 4) | text position << 4 | score: one radix sort then orders the hits by
 // read and, inside a read, by text position.
 // ------------------------------------------------------------------------------------------------
+constexpr int PLACE_INLINE = 16;
+
 __global__ void k_hit_sizes(const Node *hits, int64_t n_hits, int64_t *sizes)
 {
    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -499,29 +508,42 @@ __global__ void k_hit_sizes(const Node *hits, int64_t n_hits, int64_t *sizes)
    sizes[i] = (int64_t)hits[i].w[2] | ((int64_t)((hits[i].w[3] >> 16) & 0xff) << 32);
 }
 
-__global__ void __launch_bounds__(256) k_expand_hits(IndexDev ix, const Node *hits, int64_t n_hits, const int64_t *hit_off,
-                                                     int64_t n_locs, int pos_bits, unsigned long long *keys)
+__global__ void __launch_bounds__(256) k_place(IndexDev ix, const Node *hits, int64_t n_hits, const unsigned long long *direct,
+                                               const int64_t *sizes, const int64_t *hit_off, int pos_bits,
+                                               unsigned long long *keys, unsigned int *longer, unsigned int *n_longer, unsigned int longer_cap)
 {
-   // A block covers 256 consecutive slots: two long binary searches per block (the hits of its first and
-   // last slot), a short one per thread between them.  Entries without slots (emptied by k_verify) share
-   // their offset with the next entry; "last h with hit_off[h] <= t" skips them.
-   __shared__ int64_t s_lo, s_hi;
-   const int64_t t0 = blockIdx.x * (int64_t)256, t = t0 + threadIdx.x;
-   if (threadIdx.x == 0 || threadIdx.x == 255) {
-      const int64_t tt = threadIdx.x == 0 ? t0 : min(t0 + 255, n_locs - 1);
-      int64_t lo = 0, hi = n_hits;             // last h with hit_off[h] <= tt
-      while (hi - lo > 1) { int64_t mid = (lo + hi) >> 1; if (hit_off[mid] <= tt) lo = mid; else hi = mid; }
-      if (threadIdx.x == 0) s_lo = lo; else s_hi = lo;
+   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+   if (i >= n_hits) return;
+   const unsigned long long key = direct ? direct[i] : ~0ull;
+   if (key != ~0ull) { keys[hit_off[i]] = key; return; }
+   const int64_t sz = sizes[i];
+   if (sz == 0) return;
+   if (sz > PLACE_INLINE) {
+      const unsigned int slot = atomicAdd(n_longer, 1u);
+      if (slot < longer_cap) longer[slot] = (unsigned int)i;      // (cap = slots / PLACE_INLINE: cannot overflow)
+      return;
    }
-   __syncthreads();
-   if (t >= n_locs) return;
-   int64_t lo = s_lo, hi = s_hi + 1;
-   while (hi - lo > 1) { int64_t mid = (lo + hi) >> 1; if (hit_off[mid] <= t) lo = mid; else hi = mid; }
    NodeR h;
-   unpack_node(hits[lo], h);
-   // an entry k_verify located carries the text position itself; an interval is read from the suffix array
-   int64_t pos = h.first == (int)LOCATED ? h.fp : sa_entry(ix.sa, ix.sar_bits, h.fp + (t - hit_off[lo]));
-   keys[t] = ((unsigned long long)h.read << (pos_bits + 4)) | ((unsigned long long)pos << 4) | (unsigned long long)h.score;
+   unpack_node(hits[i], h);
+   const int64_t off = hit_off[i];
+   const unsigned long long hi = ((unsigned long long)h.read << (pos_bits + 4)) | (unsigned long long)h.score;
+   for (int64_t j = 0; j < sz; j++)
+      keys[off + j] = hi | ((unsigned long long)sa_entry(ix.sa, ix.sar_bits, h.fp + j) << 4);
+}
+
+__global__ void __launch_bounds__(256) k_place_long(IndexDev ix, const Node *hits, const int64_t *sizes, const int64_t *hit_off, int pos_bits,
+                                                    unsigned long long *keys, const unsigned int *longer, const unsigned int *n_longer)
+{
+   const unsigned int n = *n_longer;
+   for (unsigned int e = blockIdx.x; e < n; e += gridDim.x) {
+      const int64_t i = longer[e];
+      NodeR h;
+      unpack_node(hits[i], h);
+      const int64_t off = hit_off[i], sz = sizes[i];
+      const unsigned long long hi = ((unsigned long long)h.read << (pos_bits + 4)) | (unsigned long long)h.score;
+      for (int64_t j = threadIdx.x; j < sz; j += blockDim.x)    // consecutive threads read consecutive packed entries
+         keys[off + j] = hi | ((unsigned long long)sa_entry(ix.sa, ix.sar_bits, h.fp + j) << 4);
+   }
 }
 
 // CSR offsets of the reads into the sorted keys: first key of read r = lower bound of r << shift.
