@@ -18,7 +18,7 @@ struct gpumap_batch {
    int64_t n_reads = 0;
    int stride = 0;
    std::vector<int64_t> offsets;     // host copy (n_reads + 1)
-   DevBuf reads, read_len, len_row, phases, phase_rec, phase_lo, status;
+   DevBuf reads, reads4, read_len, len_row, phases, phase_rec, phase_lo, status;
    DevBuf up_src, up_off;            // staging of the upload (kept by a batch that is refilled)
    DevBuf hits, hit_sizes, hit_off, direct, longer, keys, keys_alt, read_cnt, read_first;
    DevBuf loc_read, loc_pos, loc_fwd, loc_seq, loc_seqpos, loc_strand, loc_score;
@@ -32,7 +32,7 @@ struct gpumap_batch {
    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};      // [4]: between k_search and k_verify
    void release()
    {
-      for (DevBuf *b : {&up_src, &up_off, &reads, &read_len, &len_row, &phases, &phase_rec, &phase_lo, &status, &hits, &hit_sizes, &hit_off, &direct, &longer, &keys, &keys_alt,
+      for (DevBuf *b : {&up_src, &up_off, &reads, &reads4, &read_len, &len_row, &phases, &phase_rec, &phase_lo, &status, &hits, &hit_sizes, &hit_off, &direct, &longer, &keys, &keys_alt,
                         &read_cnt, &read_first, &loc_read, &loc_pos, &loc_fwd, &loc_seq, &loc_seqpos, &loc_strand,
                         &loc_score, &hkeys, &hkeys_alt, &hidx, &hidx_alt, &hit_read, &hit_fp, &hit_rp, &hit_sz,
                         &hit_dp, &hit_score, &hit_align})
@@ -72,6 +72,7 @@ extern "C" void gpumap_destroy(gpumap_ctx *ctx)
       if (ctx->d_sa) (void)hipFree(ctx->d_sa);
    }
    if (ctx->d_jump) (void)hipFree(ctx->d_jump);
+   if (ctx->d_text4) (void)hipFree(ctx->d_text4);
    if (ctx->d_ref_occ) (void)hipFree(ctx->d_ref_occ);
    if (ctx->d_text && ctx->owns_text) (void)hipFree(ctx->d_text);
    if (ctx->d_sym_table) (void)hipFree(ctx->d_sym_table);
@@ -84,6 +85,15 @@ extern "C" void gpumap_destroy(gpumap_ctx *ctx)
 int gm_ctx_build_jump(gpumap_ctx *ctx, int k)
 {
    if (ctx->d_jump) { HIP_TRY(hipFree(ctx->d_jump)); ctx->d_jump = nullptr; ctx->jump_k = 0; }
+   if (ctx->d_text != nullptr && ctx->d_text4 == nullptr) {
+      // what k_verify compares windows of: 8 symbols per word, 32 bytes of separators behind the end
+      const int64_t words = cdiv(ctx->ix.n, 8) + 8;
+      HIP_TRY(hipMalloc(&ctx->d_text4, 4 * (size_t)words));
+      hipLaunchKernelGGL(k_pack_nibbles, dim3((unsigned)std::min<int64_t>(cdiv(words, 256), 1 << 20)), dim3(256), 0, ctx->stream,
+                         (const uint8_t *)ctx->d_text, ctx->ix.n, (uint8_t)SYMS, (uint32_t *)ctx->d_text4, words);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+   }
    if (k < 0) {
       // as many letters as keep the table at no more than one entry per text position, at most 16 (69 GB),
       // and the table within a third of the memory that is free
@@ -184,6 +194,11 @@ extern "C" gpumap_ctx *gpumap_create(const gpumap_index_view *v, int device)
       HIP_TRY(hipMalloc(&ctx->d_sa, (size_t)ctx->sa_bytes));
       HIP_TRY(hipMemset(ctx->d_sa, 0, (size_t)ctx->sa_bytes));
       HIP_TRY(hipMemcpy(ctx->d_sa, v->sa, (size_t)v->sar_len * 8, hipMemcpyHostToDevice));
+      if (v->text) {        // the text lets k_verify finish unique nodes; without it the search runs on the Occ table alone
+         HIP_TRY(hipMalloc(&ctx->d_text, (size_t)v->txt_len + 16));          // k_verify reads whole words
+         HIP_TRY(hipMemset((char *)ctx->d_text + v->txt_len, SYMS, 16));
+         HIP_TRY(hipMemcpy(ctx->d_text, v->text, (size_t)v->txt_len, hipMemcpyHostToDevice));
+      }
       // K0: upload the reference layout verbatim, repack on the device, drop the copy
       HIP_TRY(hipMalloc(&d_ref, (size_t)v->occ_length * 8));
       HIP_TRY(hipMemcpy(d_ref, v->occ, (size_t)v->occ_length * 8, hipMemcpyHostToDevice));
@@ -195,11 +210,6 @@ extern "C" gpumap_ctx *gpumap_create(const gpumap_index_view *v, int device)
       HIP_TRY(hipFree(d_c)); d_c = nullptr;
       memcpy(ctx->c_host, v->c, 8 * (SYMS + 1));
       ctx->wil_cnt = v->wil_cnt;
-      if (v->text) {        // the text lets k_verify finish unique nodes; without it the search runs on the Occ table alone
-         HIP_TRY(hipMalloc(&ctx->d_text, (size_t)v->txt_len + 16));          // k_verify reads whole words
-         HIP_TRY(hipMemset((char *)ctx->d_text + v->txt_len, SYMS, 16));
-         HIP_TRY(hipMemcpy(ctx->d_text, v->text, (size_t)v->txt_len, hipMemcpyHostToDevice));
-      }
    }
    (void)d_seq;
    return ctx;
@@ -436,10 +446,11 @@ static int batch_fill(gpumap_ctx *ctx, gpumap_batch *b, const uint8_t *src, cons
          GM_FAIL_IF(len < 0, "offsets must not decrease.");
          if (len <= MAX_READ) { b->length_seen[len] = true; maxlen = std::max(maxlen, len); }
       }
-      b->stride = (int)((maxlen + 15) & ~(int64_t)15);      // rows are read as 16-byte units
+      b->stride = (int)((maxlen + 31) & ~(int64_t)31);      // packed rows (two symbols per byte) are read as 16-byte units
       int64_t total = offsets[n_reads] - offsets[0];
       GM_FAIL_IF(total > 0 && src == nullptr, "argument 'codes' is NULL.");
       HIP_TRY(b->reads.ensure((size_t)std::max<int64_t>(1, n_reads) * b->stride));
+      HIP_TRY(b->reads4.ensure((size_t)std::max<int64_t>(1, n_reads) * (b->stride / 2)));
       HIP_TRY(b->read_len.ensure(2 * (size_t)std::max<int64_t>(1, n_reads)));
       HIP_TRY(b->status.ensure(8 * (size_t)std::max<int64_t>(1, n_reads)));
       for (auto &e : b->ev) if (!e) HIP_TRY(hipEventCreate(&e));
@@ -455,6 +466,9 @@ static int batch_fill(gpumap_ctx *ctx, gpumap_batch *b, const uint8_t *src, cons
                             b->up_src.as<const uint8_t>(), b->up_off.as<const int64_t>(), n_reads, b->stride,
                             is_text ? (const uint8_t *)ctx->d_sym_table : (const uint8_t *)nullptr,
                             b->reads.as<uint8_t>(), b->read_len.as<uint16_t>(), (uint8_t *)nullptr);
+         const int64_t words = n_reads * (b->stride / 8);
+         hipLaunchKernelGGL(k_pack_nibbles, dim3((unsigned)std::min<int64_t>(cdiv(words, 256), 1 << 20)), dim3(256), 0, ctx->stream,
+                            b->reads.as<const uint8_t>(), n_reads * b->stride, (uint8_t)0xff, b->reads4.as<uint32_t>(), words);
          HIP_TRY(hipGetLastError());
          HIP_TRY(hipStreamSynchronize(ctx->stream));
       }
@@ -568,7 +582,7 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
       unsigned long long host_cnt[8 + 64];
       memset(host_cnt, 0, sizeof host_cnt);
       // interval output needs the final interval of every hit: no short cut through the text then
-      const bool use_verify = ctx->verify && ctx->d_text != nullptr && !want_intervals;
+      const bool use_verify = ctx->verify && ctx->d_text != nullptr && ctx->d_text4 != nullptr && !want_intervals;
       size_t hit_cap = std::max<size_t>((size_t)1 << 16, (size_t)R * (use_verify ? (size_t)tau + 3 : 2));
       HIP_TRY(hipEventRecord(b->ev[0], st));
       for (int attempt = 0; attempt < 2; attempt++) {
@@ -614,7 +628,8 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
          HIP_TRY(b->direct.ensure(8 * (size_t)H));
          HIP_TRY(hipMemsetAsync(b->hit_sizes.as<int64_t>() + H, 0, 8, st));
          VerifyArgs V;
-         V.ix = ctx->ix; V.text = (const uint8_t *)ctx->d_text;
+         V.ix = ctx->ix; V.text = (const uint8_t *)ctx->d_text; V.text4 = (const uint8_t *)ctx->d_text4;
+         V.reads4 = b->reads4.as<const uint8_t>();
          V.reads = b->reads.as<const uint8_t>(); V.read_len = b->read_len.as<const uint16_t>();
          V.phase_rec = b->phase_rec.as<const uint2>(); V.phase_lo = b->phase_lo.as<const uint8_t>();
          V.list = b->hits.as<const Node>(); V.n_list = H; V.stride = b->stride; V.n_ext = cnt + 8;

@@ -198,6 +198,29 @@ __global__ void k_encode(const uint8_t *src, const int64_t *offsets, int64_t n_r
    }
 }
 
+// Two symbols per byte (the first in the low half) for the windows k_verify compares: half the lines
+// per window.  src holds n_src bytes (codes 0..5, or 0xff behind the end of a read); what lies behind is
+// written as `fill`.  One thread per 8 symbols.
+__global__ void k_pack_nibbles(const uint8_t *src, int64_t n_src, uint8_t fill, uint32_t *dst, int64_t n_words)
+{
+   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_words; i += (int64_t)gridDim.x * blockDim.x) {
+      uint32_t a, b;
+      if (8 * i + 8 <= n_src) {
+         const uint2 v = *reinterpret_cast<const uint2 *>(src + 8 * i);
+         a = v.x; b = v.y;
+      } else {
+         a = b = 0;
+         for (int k = 0; k < 8; k++) {
+            const uint32_t c = 8 * i + k < n_src ? src[8 * i + k] : fill;
+            if (k < 4) a |= c << (8 * k); else b |= c << (8 * (k - 4));
+         }
+      }
+      const uint32_t pa = (a & 0xfu) | ((a >> 4) & 0xf0u) | ((a >> 8) & 0xf00u) | ((a >> 12) & 0xf000u);
+      const uint32_t pb = (b & 0xfu) | ((b >> 4) & 0xf0u) | ((b >> 8) & 0xf00u) | ((b >> 12) & 0xf000u);
+      dst[i] = pa | (pb << 16);
+   }
+}
+
 // Flat variant for gpumap_encode: sym_str_index (src/index_sym.c:293-319) over a whole buffer.
 __global__ void k_encode_flat(const uint8_t *src, int64_t n, const uint8_t *table, uint8_t *dst)
 {
@@ -248,7 +271,9 @@ struct SearchArgs {
 struct VerifyArgs {
    IndexDev ix;
    const uint8_t  *text;        // [n] codes 0..5
+   const uint8_t  *text4;       // the same, two symbols per byte (k_pack_nibbles), 32 bytes of padding behind
    const uint8_t  *reads;
+   const uint8_t  *reads4;      // [n_reads][stride / 2] the rows of `reads`, two symbols per byte
    const uint16_t *read_len;
    const uint2    *phase_rec;   // [rows][MAX_PHASES]
    const uint8_t  *phase_lo;    // [rows][MAX_PHASES]
@@ -261,12 +286,13 @@ struct VerifyArgs {
    int key_shift;                  // key = read << key_shift | text position << 4 | score (as k_place)
 };
 
-// The query row and the text window of a candidate are read as 16-byte units (every lane of a load
-// touches a line of its own, so the number of load instructions is what the cache pays for) and
-// compared a word at a time in registers; what is kept is one bit per letter: E = the letter costs a
-// mismatch (text and query differ and the query letter is not N), S = the text holds a separator
-// there.  The walk then goes from event to event with ffs / clz on those bits: plain matches between
-// events are counted, not visited.  NCH = 64-letter pieces of the longest read of the batch.
+// The query row and the text window of a candidate are read as 16-byte units of 32 symbols (four bits
+// per symbol; every lane of a load touches a line of its own, so the number of load instructions and of
+// lines is what the memory path pays for) and compared a word at a time in registers; what is kept is
+// one bit per letter: E = the letter costs a mismatch (text and query differ and the query letter is
+// not N), S = the text holds a separator there.  The walk then goes from event to event with
+// ffs / clz on those bits: plain matches between events are counted, not visited.
+// NCH = 64-letter pieces of the longest read of the batch.
 __device__ __forceinline__ uint32_t sel4w(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t j)
 {
    uint32_t r = a;
@@ -304,44 +330,47 @@ __global__ void __launch_bounds__(256) k_verify(VerifyArgs A)
       uint64_t E[NCH], S[NCH];
 #pragma unroll
       for (int c = 0; c < NCH; c++) { E[c] = 0; S[c] = 0; }
-      const int nq = (m + 15) >> 4;                                            // 16-letter units of the query row
-      // whole units inside the text buffer (16 bytes of padding behind the text) and the window inside the text
-      bool fast = p0 >= 0 && p0 + m <= A.ix.n && 16 * ((p0 >> 4) + nq + 1) <= A.ix.n + 16;
+      const int nq = (m + 31) >> 5;                                            // 32-letter units of the query row
+      // the window inside the text (the packed text has 32 bytes of padding: whole units can be read)
+      bool fast = p0 >= 0 && p0 + m <= A.ix.n;
       if (fast) {
-         const uint4 *q16 = reinterpret_cast<const uint4 *>(A.reads + (size_t)read * A.stride);
-         const uint4 *t16 = reinterpret_cast<const uint4 *>(A.text) + (p0 >> 4);
-         const uint32_t ws = (uint32_t)(p0 >> 2) & 3, sh = (uint32_t)p0 & 3;
+         const uint4 *q16 = reinterpret_cast<const uint4 *>(A.reads4 + (size_t)read * (size_t)(A.stride >> 1));
+         const uint4 *t16 = reinterpret_cast<const uint4 *>(A.text4) + (p0 >> 5);
+         const uint32_t ws = (uint32_t)(p0 >> 3) & 3, bs = 4 * ((uint32_t)p0 & 7);   // word and bit offset of the window in its unit
          uint32_t sepacc = 0;
          uint4 carry = t16[0];
 #pragma unroll
          for (int c = 0; c < NCH; c++) {
-            if (4 * c < nq) {
-               uint32_t T[20], Q[16];
+            if (2 * c < nq) {
+               uint32_t T[12], Q[8];
                T[0] = carry.x; T[1] = carry.y; T[2] = carry.z; T[3] = carry.w;
 #pragma unroll
-               for (int j = 0; j < 4; j++) {
+               for (int j = 0; j < 2; j++) {
                   uint4 tv = make_uint4(0, 0, 0, 0), qv = make_uint4(0, 0, 0, 0);
-                  if (4 * c + j < nq) { tv = t16[4 * c + j + 1]; qv = q16[4 * c + j]; }
+                  if (2 * c + j < nq) { tv = t16[2 * c + j + 1]; qv = q16[2 * c + j]; }
                   T[4 + 4 * j] = tv.x; T[5 + 4 * j] = tv.y; T[6 + 4 * j] = tv.z; T[7 + 4 * j] = tv.w;
                   Q[4 * j] = qv.x; Q[4 * j + 1] = qv.y; Q[4 * j + 2] = qv.z; Q[4 * j + 3] = qv.w;
                }
-               carry = make_uint4(T[16], T[17], T[18], T[19]);
-               uint32_t X[17];
+               carry = make_uint4(T[8], T[9], T[10], T[11]);
+               uint32_t X[9];
 #pragma unroll
-               for (int j = 0; j < 17; j++) X[j] = sel4w(T[j], T[j + 1], T[j + 2], T[j + 3], ws);
+               for (int j = 0; j < 9; j++) X[j] = sel4w(T[j], T[j + 1], T[j + 2], T[j + 3], ws);
                uint32_t half[2] = {0, 0};
 #pragma unroll
-               for (int w = 0; w < 16; w++) {
-                  const uint32_t tw = __builtin_amdgcn_alignbyte(X[w + 1], X[w], sh), qw = Q[w];
+               for (int w = 0; w < 8; w++) {
+                  const uint32_t tw = __builtin_amdgcn_alignbit(X[w + 1], X[w], bs), qw = Q[w];
                   const uint32_t x = qw ^ tw;
-                  const uint32_t d = (x | (x >> 1) | (x >> 2)) & ~(qw >> 2) & 0x01010101u;   // letters that cost a mismatch
-                  sepacc |= (tw >> 2) & tw;                                                  // bit 0 of a byte: code 5
-                  half[w >> 3] |= ((d * 0x01020408u) >> 24) << (4 * (w & 7));                // bits 0,8,16,24 -> 0,1,2,3
+                  uint32_t d = (x | (x >> 1) | (x >> 2)) & ~(qw >> 2) & 0x11111111u;          // letters that cost a mismatch
+                  sepacc |= (tw >> 2) & tw;                                                  // bit 0 of a symbol: code 5
+                  d = (d | (d >> 3)) & 0x03030303u;                                          // bits 0,4,..,28 -> 0..7
+                  d = (d | (d >> 6)) & 0x000f000fu;
+                  d = (d | (d >> 12)) & 0xffu;
+                  half[w >> 2] |= d << (8 * (w & 3));
                }
                E[c] = (uint64_t)half[0] | ((uint64_t)half[1] << 32);
             }
          }
-         if (sepacc & 0x01010101u) fast = false;           // a separator in (or just behind) the window
+         if (sepacc & 0x11111111u) fast = false;           // a separator in (or just behind) the window
       }
       if (!fast) {
          // a window over an end of the text or over a separator: letter by letter, separators outside the text
