@@ -583,7 +583,10 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
       memset(host_cnt, 0, sizeof host_cnt);
       // interval output needs the final interval of every hit: no short cut through the text then
       const bool use_verify = ctx->verify && ctx->d_text != nullptr && ctx->d_text4 != nullptr && !want_intervals;
-      size_t hit_cap = std::max<size_t>((size_t)1 << 16, (size_t)R * (use_verify ? (size_t)tau + 3 : 2));
+      // first guess of the list's length (a batch that is run or refilled again keeps the longer list): with
+      // k_verify every seed can leave a candidate, plus what repeats add (5.5 entries per read at GRCh38
+      // size, tau 2); too short costs a second run of the search
+      size_t hit_cap = std::max<size_t>((size_t)1 << 16, (size_t)R * (use_verify ? (size_t)tau + 4 : 2));
       HIP_TRY(hipEventRecord(b->ev[0], st));
       for (int attempt = 0; attempt < 2; attempt++) {
          HIP_TRY(b->hits.ensure(hit_cap * sizeof(Node)));
@@ -706,10 +709,8 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
          for (DevBuf *x : {&b->loc_read, &b->loc_pos, &b->loc_fwd, &b->loc_seq, &b->loc_seqpos}) HIP_TRY(x->ensure(8 * (size_t)L));
          HIP_TRY(b->loc_strand.ensure((size_t)L));
          HIP_TRY(b->loc_score.ensure((size_t)L));
-         hipLaunchKernelGGL(k_read_first, dim3((unsigned)cdiv(R + 1, 256)), dim3(256), 0, st, (const unsigned long long *)db.Current(),
-                            L, R, pos_bits + 4, b->read_first.as<int64_t>());
          hipLaunchKernelGGL(k_unpack_locs, dim3((unsigned)cdiv(L, 256)), dim3(256), 0, st, ctx->ix,
-                            (const unsigned long long *)db.Current(), L, pos_bits, b->loc_read.as<int64_t>(),
+                            (const unsigned long long *)db.Current(), L, pos_bits, R, b->read_first.as<int64_t>(), b->loc_read.as<int64_t>(),
                             b->loc_pos.as<int64_t>(), b->loc_fwd.as<int64_t>(), b->loc_seq.as<int64_t>(),
                             b->loc_seqpos.as<int64_t>(), b->loc_strand.as<uint8_t>(), b->loc_score.as<uint8_t>());
          HIP_TRY(hipGetLastError());

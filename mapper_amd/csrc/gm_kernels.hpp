@@ -575,28 +575,23 @@ __global__ void __launch_bounds__(256) k_place_long(IndexDev ix, const Node *hit
    }
 }
 
-// CSR offsets of the reads into the sorted keys: first key of read r = lower bound of r << shift.
-__global__ void k_read_first(const unsigned long long *keys, int64_t n_locs, int64_t n_reads, int shift, int64_t *read_first)
-{
-   int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-   if (r > n_reads) return;
-   const unsigned long long want = (unsigned long long)r << shift;
-   int64_t lo = 0, hi = n_locs;                // first t with keys[t] >= want
-   while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (keys[mid] < want) lo = mid + 1; else hi = mid; }
-   read_first[r] = lo;
-}
-
 // Sorted keys -> structure of arrays; strand and coordinates by the rule of txt_pos_to_str
-// (src/index_txt.c:492-505) with seq_bisect (:770-787).
-__global__ void k_unpack_locs(IndexDev ix, const unsigned long long *keys, int64_t n_locs, int pos_bits,
-                              int64_t *loc_read, int64_t *loc_pos, int64_t *loc_fwd, int64_t *loc_seq,
+// (src/index_txt.c:492-505) with seq_bisect (:770-787).  Also the CSR offsets of the reads: the thread of
+// the first key of a read writes that read's offset and those of the reads without hits before it.
+__global__ void k_unpack_locs(IndexDev ix, const unsigned long long *keys, int64_t n_locs, int pos_bits, int64_t n_reads,
+                              int64_t *read_first, int64_t *loc_read, int64_t *loc_pos, int64_t *loc_fwd, int64_t *loc_seq,
                               int64_t *loc_seqpos, uint8_t *loc_strand, uint8_t *loc_score)
 {
    int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
    if (t >= n_locs) return;
    unsigned long long k = keys[t];
    int64_t pos = (int64_t)((k >> 4) & ((1ull << pos_bits) - 1ull));
-   loc_read[t] = (int64_t)(k >> (pos_bits + 4));
+   const int64_t read = (int64_t)(k >> (pos_bits + 4));
+   const int64_t before = t == 0 ? -1 : (int64_t)(keys[t - 1] >> (pos_bits + 4));
+   for (int64_t r = before + 1; r <= read; r++) read_first[r] = t;
+   if (t == n_locs - 1)
+      for (int64_t r = read + 1; r <= n_reads; r++) read_first[r] = n_locs;
+   loc_read[t] = read;
    loc_pos[t] = pos;
    loc_score[t] = (uint8_t)(k & 15);
    int strand = pos >= ix.n / 2;
