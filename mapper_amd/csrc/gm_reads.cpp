@@ -169,7 +169,17 @@ int64_t gm_reads_next(gm_read_stream *s, size_t max_bytes, gm_read_chunk *chunk)
             const char *q = base + a, *e = base + b;
             while (q < e && (q = (const char *)memchr(q, '\n', (size_t)(e - q))) != nullptr) { v.push_back((uint64_t)(q - base) + 1); q++; }
          });
-         for (auto &v : part) { eol.insert(eol.end(), v.begin(), v.end()); v.clear(); }
+         {  // the slices' line ends one after another (copied side by side: 4 M entries per chunk)
+            std::vector<size_t> at(part.size() + 1, eol.size());
+            for (size_t t = 0; t < part.size(); t++) at[t + 1] = at[t] + part[t].size();
+            eol.resize(at.back());
+            auto copy = [&](size_t t) {
+               if (!part[t].empty()) memcpy(eol.data() + at[t], part[t].data(), 8 * part[t].size());
+               part[t].clear();
+            };
+            if (at.back() - at[0] >= ((size_t)1 << 16)) gm_parallel_for((int)part.size(), [&](int t) { copy((size_t)t); });
+            else for (size_t t = 0; t < part.size(); t++) copy(t);
+         }
          scanned = hi;
          // first record boundary with max_bytes or more behind it
          size_t k = (size_t)(std::lower_bound(eol.begin(), eol.end(), (uint64_t)std::max<size_t>(max_bytes, 1)) - eol.begin());   // lines 0..k hold >= max_bytes
