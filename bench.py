@@ -234,7 +234,7 @@ def main():
                                                         "time: a rate of work retired, not a traffic (can exceed the HBM peak)"}},
             "stages_ms": {"search": c["ms_search"], "locate": c["ms_locate"], "order": c["ms_sort"],
                           "total": c["ms_total"]},
-            "hits_per_batch": {"list_entries": c["n_hits"], "located": c["n_locs"]},
+            "hits_per_batch": {"list_entries": c["n_hits"], "list_length": c["list_length"], "located": c["n_locs"]},
             "occupancy": {"loop_passes": c["loop_passes"], "continuations": c["continuations"],
                           "steps_from_jump_table": c["jumped_steps"], "steps_replayed_on_text": c["verify_steps"],
                           "steps_on_occ_table": c["n_ext"] - c["jumped_steps"] - c["verify_steps"],

@@ -297,7 +297,7 @@ extern "C" int gpumap_set_option(gpumap_ctx *ctx, const char *name, int64_t valu
    GM_FAIL_IF(ctx == nullptr || name == nullptr, "NULL argument.");
    if (!strcmp(name, "waves_per_cu")) { GM_FAIL_IF(value < 0 || value > 32, "waves_per_cu out of range."); ctx->waves_per_cu = (int)value; }
    else if (!strcmp(name, "pinned_results")) ctx->pinned_results = value != 0;
-   else if (!strcmp(name, "verify")) ctx->verify = value != 0;
+   else if (!strcmp(name, "verify")) { GM_FAIL_IF(value < -1 || value > 2, "verify out of range."); ctx->verify = (int)value; }
    else if (!strcmp(name, "jump_k")) { HIP_TRY(hipSetDevice(ctx->device)); GM_FAIL_IF(gm_ctx_build_jump(ctx, (int)value) != 0, "cannot build the jump table."); }
    else if (!strcmp(name, "spill_nodes")) { GM_FAIL_IF(value < 0 || value > (1 << 22), "spill_nodes out of range."); ctx->spill_cap = value ? ((value + SPILL_CHUNK - 1) / SPILL_CHUNK) * SPILL_CHUNK : 16384; }
    else GM_FAIL("unknown option.");
@@ -582,7 +582,11 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
       unsigned long long host_cnt[8 + 64];
       memset(host_cnt, 0, sizeof host_cnt);
       // interval output needs the final interval of every hit: no short cut through the text then
-      const bool use_verify = ctx->verify && ctx->d_text != nullptr && ctx->d_text4 != nullptr && !want_intervals;
+      // 0: every step on the Occ table; 1: nodes of one suffix are finished on the text; 2: also nodes of two.
+      // -1 (default): 2 for texts of 2^31 symbols and more, else 1 (measured: pairs pay where most k-mers of
+      // the jump table's length occur more than once; +8 % at GRCh38 size, -13 % at chr21 size)
+      const int verify_mode = ctx->verify >= 0 ? ctx->verify : (ctx->ix.n >= ((int64_t)1 << 31) ? 2 : 1);
+      const int use_verify = (verify_mode && ctx->d_text != nullptr && ctx->d_text4 != nullptr && !want_intervals) ? verify_mode : 0;
       // first guess of the list's length (a batch that is run or refilled again keeps the longer list): with
       // k_verify every seed can leave a candidate, plus what repeats add (5.5 entries per read at GRCh38
       // size, tau 2); too short costs a second run of the search
@@ -601,7 +605,7 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
          A.cursor = cnt + 0; A.hits = b->hits.as<Node>(); A.hit_cap = hit_cap; A.hit_count = cnt + 1; A.n_ext = cnt + 2;
          A.spill = ctx->spill.as<Node>(); A.spill_cap = (uint32_t)ctx->spill_cap; A.error = (int *)(cnt + 3); A.stats = cnt + 4;
          A.jump = (const uint4 *)ctx->d_jump; A.jump_k = ctx->jump_k;
-         A.verify = use_verify ? 1 : 0;
+         A.verify = use_verify;
          {
             const int rpr = 64 / (tau + 1);
             int64_t k = R / std::max<int64_t>(1, n_waves * 8 * rpr);           // at least 8 reservations per wave: balance at the end
@@ -623,12 +627,12 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
       const int read_bits = bits_for((uint64_t)std::max<int64_t>(R, 1));
       GM_FAIL_IF(pos_bits + 4 + read_bits > 64, "batch too large for the 64-bit sort key (split the batch).");
       HIP_TRY(hipEventRecord(b->ev[4], st));
-      const bool verified = use_verify && host_cnt[1] > 0;
+      const bool verified = use_verify != 0 && host_cnt[1] > 0;
       if (verified) {
          const int64_t H = (int64_t)host_cnt[1];
          GM_FAIL_IF(H >= ((int64_t)1 << 31), "too many entries in the hit list (split the batch).");
          HIP_TRY(b->hit_sizes.ensure(8 * (size_t)(H + 1)));
-         HIP_TRY(b->direct.ensure(8 * (size_t)H));
+         HIP_TRY(b->direct.ensure(16 * (size_t)H));
          HIP_TRY(hipMemsetAsync(b->hit_sizes.as<int64_t>() + H, 0, 8, st));
          VerifyArgs V;
          V.ix = ctx->ix; V.text = (const uint8_t *)ctx->d_text; V.text4 = (const uint8_t *)ctx->d_text4;
@@ -639,13 +643,17 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
          V.direct = b->direct.as<unsigned long long>(); V.sizes = b->hit_sizes.as<int64_t>();
          V.key_shift = pos_bits + 4;
          const int vbd = 256;
-         const dim3 vgrid((unsigned)cdiv(V.n_list, vbd));
+         const bool pairs = use_verify == 2;                             // two lanes per entry
+         const dim3 vgrid((unsigned)cdiv((pairs ? 2 : 1) * V.n_list, vbd));
+#define GM_VERIFY(N) do { if (pairs) hipLaunchKernelGGL((k_verify<N, true>), vgrid, dim3(vbd), 0, st, V); \
+                          else hipLaunchKernelGGL((k_verify<N, false>), vgrid, dim3(vbd), 0, st, V); } while (0)
          switch (cdiv(b->stride, 64)) {                                 // 64-letter pieces of the longest read
-            case 1:  hipLaunchKernelGGL(k_verify<1>, vgrid, dim3(vbd), 0, st, V); break;
-            case 2:  hipLaunchKernelGGL(k_verify<2>, vgrid, dim3(vbd), 0, st, V); break;
-            case 3:  hipLaunchKernelGGL(k_verify<3>, vgrid, dim3(vbd), 0, st, V); break;
-            default: hipLaunchKernelGGL(k_verify<4>, vgrid, dim3(vbd), 0, st, V); break;
+            case 1:  GM_VERIFY(1); break;
+            case 2:  GM_VERIFY(2); break;
+            case 3:  GM_VERIFY(3); break;
+            default: GM_VERIFY(4); break;
          }
+#undef GM_VERIFY
          HIP_TRY(hipGetLastError());
          HIP_TRY(hipMemcpyAsync(host_cnt, cnt, sizeof host_cnt, hipMemcpyDeviceToHost, st));
          HIP_TRY(hipStreamSynchronize(st));

@@ -253,7 +253,7 @@ struct SearchArgs {
                                 // [2] extension steps the jump table stood in for, [3] entries of the list that are not holes
    const uint4 *jump;           // jump table (k_build_jump) or nullptr
    int jump_k;
-   int verify;                  // nodes with sz == 1 leave as candidates for k_verify
+   int verify;                  // nodes with sz <= verify (0, 1 or 2) leave as candidates for k_verify
    uint32_t cursor_chunk;       // reads a wave reserves per atomic on the cursor (a multiple of its refill)
 };
 
@@ -281,8 +281,8 @@ struct VerifyArgs {
    int64_t n_list;
    int stride;
    unsigned long long *n_ext;      // [64] partial sums (one hot address would serialise the waves)
-   unsigned long long *direct;     // [n_list] sort key of the hit a candidate became, ~0 for every other entry
-   int64_t *sizes;                 // [n_list] slots of the entry in the located output: 1 for such a hit, the suffixes of an interval
+   unsigned long long *direct;     // [n_list][2] sort keys of the hits a candidate (one or two suffixes) became, ~0 = none
+   int64_t *sizes;                 // [n_list] slots of the entry in the located output: such hits, or the suffixes of an interval
    int key_shift;                  // key = read << key_shift | text position << 4 | score (as k_place)
 };
 
@@ -302,34 +302,86 @@ __device__ __forceinline__ uint32_t sel4w(uint32_t a, uint32_t b, uint32_t c, ui
    return r;
 }
 
+// First event of mask E (NCH 64-letter pieces) in the letters a..b, seen from a (up) or from b (down); -1: none.
 template <int NCH>
+__device__ __forceinline__ int first_event(const uint64_t (&E)[NCH], int a, int b, bool up)
+{
+   int first = -1, last = -1;
+#pragma unroll
+   for (int c = 0; c < NCH; c++) {
+      const int l = max(a - 64 * c, 0), h = min(b - 64 * c, 63);
+      if (l <= h) {
+         const uint64_t mk = E[c] & (~0ull << l) & (~0ull >> (63 - h));
+         if (mk) {
+            if (first < 0) first = 64 * c + __ffsll((unsigned long long)mk) - 1;
+            last = 64 * c + 63 - __clzll((long long)mk);
+         }
+      }
+   }
+   return up ? first : last;
+}
+
+template <int NCH>
+__device__ __forceinline__ bool test_bit(const uint64_t (&E)[NCH], int pos)
+{
+   bool r = false;
+#pragma unroll
+   for (int c = 0; c < NCH; c++) if ((pos >> 6) == c) r = (E[c] >> (pos & 63)) & 1;
+   return r;
+}
+
+// PAIRS: two lanes per entry of the list.  An entry that is a candidate then holds one or two suffixes;
+// lane q of the pair replays suffix q.  The two walks of a pair share the nodes of the reference's search
+// tree as long as the two places of the text spell the same letters along the walk: those steps are
+// counted once.  Without PAIRS every candidate holds one suffix and an entry has one lane.
+template <int NCH, bool PAIRS>
 __global__ void __launch_bounds__(256) k_verify(VerifyArgs A)
 {
-   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-   uint32_t steps = 0;
+   constexpr bool pairs = PAIRS;
+   const int64_t th = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+   const int64_t i = PAIRS ? th >> 1 : th;
+   const int q = PAIRS ? (int)(th & 1) : 0;
+   uint32_t steps = 0;                 // this walk's steps (0 for a lane without a suffix)
    unsigned long long key = ~0ull;
-   if (i < A.n_list && !(A.list[i].w[5] >> META_CAND)) {
-      const Node &e = A.list[i];
-      A.sizes[i] = (int64_t)e.w[2] | ((int64_t)((e.w[3] >> 16) & 0xff) << 32);
-      A.direct[i] = key;
+   bool cand = false, pair = false;
+   int64_t p0 = 0;
+   uint32_t read = 0;
+   int row = 0, m = 0;
+   int phase0 = 0, pos0 = 0, end0 = 0;
+   bool fw0 = false;
+   uint64_t E[NCH], S[NCH], QN[NCH];
+#pragma unroll
+   for (int c = 0; c < NCH; c++) { E[c] = 0; S[c] = 0; QN[c] = 0; }
+   if (i < A.n_list) {
+      const uint32_t w5 = A.list[i].w[5];
+      cand = w5 >> META_CAND;
+      if (!cand && q == 0) {
+         const Node &e = A.list[i];
+         A.sizes[i] = (int64_t)e.w[2] | ((int64_t)((e.w[3] >> 16) & 0xff) << 32);
+         *reinterpret_cast<ulonglong2 *>(A.direct + 2 * i) = make_ulonglong2(~0ull, ~0ull);
+      }
    }
-   if (i < A.n_list && (A.list[i].w[5] >> META_CAND)) {
+   bool mine = false;                  // this lane replays a suffix
+   if (cand) {
       Node nd = A.list[i];
-      const int64_t fp = (int64_t)nd.w[0] | ((int64_t)(nd.w[3] & 0xff) << 32);
+      pair = PAIRS && nd.w[2] == 2;
+      mine = q == 0 || pair;
+   }
+   if (mine) {
+      Node nd = A.list[i];
+      const int64_t fp = ((int64_t)nd.w[0] | ((int64_t)(nd.w[3] & 0xff) << 32)) + q;
       int pos = (int)(nd.w[3] >> 24);
       uint32_t meta = nd.w[5] & ~(1u << META_CAND);
-      const uint32_t read = nd.w[4];
-      const int row = (int)(nd.w[7] >> 24);
-      const int m = A.read_len[read];
+      read = nd.w[4];
+      row = (int)(nd.w[7] >> 24);
+      m = A.read_len[read];
       int phase = (int)(meta & 63);
       bool fw = (meta >> META_FW) & 1, dash = (meta >> META_DASH) & 1;
       int end = (meta >> META_END) & 255, tau = (meta >> META_TAU) & 7, diff = (meta >> META_DIFF) & 7;
       int score = (meta >> META_SCORE) & 7, sref = (meta >> META_SREF) & 7;
+      phase0 = phase; pos0 = pos; end0 = end; fw0 = fw;
       const int lo = fw ? A.phase_lo[row * MAX_PHASES + phase] : pos + 1;      // lowest query position matched so far
-      const int64_t p0 = sa_entry(A.ix.sa, A.ix.sar_bits, fp) - lo;              // text position of query position 0
-      uint64_t E[NCH], S[NCH];
-#pragma unroll
-      for (int c = 0; c < NCH; c++) { E[c] = 0; S[c] = 0; }
+      p0 = sa_entry(A.ix.sa, A.ix.sar_bits, fp) - lo;                            // text position of query position 0
       const int nq = (m + 31) >> 5;                                            // 32-letter units of the query row
       // the window inside the text (the packed text has 32 bytes of padding: whole units can be read)
       bool fast = p0 >= 0 && p0 + m <= A.ix.n;
@@ -355,19 +407,27 @@ __global__ void __launch_bounds__(256) k_verify(VerifyArgs A)
                uint32_t X[9];
 #pragma unroll
                for (int j = 0; j < 9; j++) X[j] = sel4w(T[j], T[j + 1], T[j + 2], T[j + 3], ws);
-               uint32_t half[2] = {0, 0};
+               uint32_t half[2] = {0, 0}, nhalf[2] = {0, 0};
 #pragma unroll
                for (int w = 0; w < 8; w++) {
                   const uint32_t tw = __builtin_amdgcn_alignbit(X[w + 1], X[w], bs), qw = Q[w];
                   const uint32_t x = qw ^ tw;
-                  uint32_t d = (x | (x >> 1) | (x >> 2)) & ~(qw >> 2) & 0x11111111u;          // letters that cost a mismatch
+                  uint32_t nn = (qw >> 2) & 0x11111111u;                                      // query N
+                  uint32_t d = (x | (x >> 1) | (x >> 2)) & ~nn & 0x11111111u;                // letters that cost a mismatch
                   sepacc |= (tw >> 2) & tw;                                                  // bit 0 of a symbol: code 5
                   d = (d | (d >> 3)) & 0x03030303u;                                          // bits 0,4,..,28 -> 0..7
                   d = (d | (d >> 6)) & 0x000f000fu;
                   d = (d | (d >> 12)) & 0xffu;
                   half[w >> 2] |= d << (8 * (w & 3));
+                  if (pair) {                                                                // (needed to tell where the pair parts)
+                     nn = (nn | (nn >> 3)) & 0x03030303u;
+                     nn = (nn | (nn >> 6)) & 0x000f000fu;
+                     nn = (nn | (nn >> 12)) & 0xffu;
+                     nhalf[w >> 2] |= nn << (8 * (w & 3));
+                  }
                }
                E[c] = (uint64_t)half[0] | ((uint64_t)half[1] << 32);
+               QN[c] = (uint64_t)nhalf[0] | ((uint64_t)nhalf[1] << 32);
             }
          }
          if (sepacc & 0x11111111u) fast = false;           // a separator in (or just behind) the window
@@ -375,17 +435,18 @@ __global__ void __launch_bounds__(256) k_verify(VerifyArgs A)
       if (!fast) {
          // a window over an end of the text or over a separator: letter by letter, separators outside the text
 #pragma unroll
-         for (int c = 0; c < NCH; c++) { E[c] = 0; S[c] = 0; }
-         for (int q = 0; q < m; q++) {
-            const int64_t tp = p0 + q;
+         for (int c = 0; c < NCH; c++) { E[c] = 0; S[c] = 0; QN[c] = 0; }
+         for (int k = 0; k < m; k++) {
+            const int64_t tp = p0 + k;
             const int t = (tp < 0 || tp >= A.ix.n) ? SYMS : A.text[tp];
-            const int qc = A.reads[(size_t)read * A.stride + q];
-            const uint64_t bit = 1ull << (q & 63);
+            const int qc = A.reads[(size_t)read * A.stride + k];
+            const uint64_t bit = 1ull << (k & 63);
 #pragma unroll
             for (int c = 0; c < NCH; c++) {
-               if ((q >> 6) == c) {
+               if ((k >> 6) == c) {
                   if (t == SYMS) S[c] |= bit;
                   if (t == SYMS || (qc != UNKNOWN && t != qc)) E[c] |= bit;     // text N against a base costs one; query N is free
+                  if (qc == UNKNOWN) QN[c] |= bit;
                }
             }
          }
@@ -395,21 +456,7 @@ __global__ void __launch_bounds__(256) k_verify(VerifyArgs A)
          // one phase: positions pos .. end in the phase's direction
          for (;;) {
             const int a = fw ? pos : end, b = fw ? end : pos;
-            int first = -1, last = -1;
-            bool sep_first = false, sep_last = false;
-#pragma unroll
-            for (int c = 0; c < NCH; c++) {
-               const int l = max(a - 64 * c, 0), h = min(b - 64 * c, 63);
-               if (l <= h) {
-                  const uint64_t mk = E[c] & (~0ull << l) & (~0ull >> (63 - h));
-                  if (mk) {
-                     const int f = __ffsll((unsigned long long)mk) - 1, g = 63 - __clzll((long long)mk);
-                     if (first < 0) { first = 64 * c + f; sep_first = (S[c] >> f) & 1; }
-                     last = 64 * c + g; sep_last = (S[c] >> g) & 1;
-                  }
-               }
-            }
-            const int e = fw ? first : last;
+            const int e = first_event<NCH>(E, a, b, fw);
             if (e < 0) {                                 // plain matches up to the end of the phase
                steps += (uint32_t)(b - a + 1);
                pos = end;
@@ -419,7 +466,7 @@ __global__ void __launch_bounds__(256) k_verify(VerifyArgs A)
             // plain matches up to the first letter where something happens, then that letter by the rules
             steps += (uint32_t)(fw ? e - pos : pos - e) + 1;
             pos = e;
-            if (fw ? sep_first : sep_last) { alive = false; break; }     // separator: no child at all
+            if (test_bit<NCH>(S, e)) { alive = false; break; }           // separator: no child at all
             if (dash) { alive = false; break; }
             const int s = score + 1;
             if (s > tau) { alive = false; break; }
@@ -440,9 +487,62 @@ __global__ void __launch_bounds__(256) k_verify(VerifyArgs A)
       }
       // a hit: the text position of the read's first letter, one suffix; or nothing
       if (final) key = ((unsigned long long)read << A.key_shift) | ((unsigned long long)p0 << 4) | (unsigned long long)score;
-      A.direct[i] = key;
-      A.sizes[i] = final ? 1 : 0;
    }
+   // ---- the pair: what the partner found (lanes 2k and 2k+1 of a wave; every lane takes part in the exchange)
+   unsigned long long key_o = ~0ull;
+   uint32_t steps_o = 0, shared = 0;
+   int64_t p0_o = 0;
+   uint64_t Eo[NCH];
+#pragma unroll
+   for (int c = 0; c < NCH; c++) Eo[c] = 0;
+   if (pairs) {
+      key_o = __shfl_xor(key, 1);
+      steps_o = (uint32_t)__shfl_xor((int)steps, 1);
+      p0_o = __shfl_xor(p0, 1);
+#pragma unroll
+      for (int c = 0; c < NCH; c++) Eo[c] = __shfl_xor(E[c], 1);
+   }
+   if (pair && q == 1) {
+      // steps the two walks have in common: the positions of the walk up to and including the first one at
+      // which the two places of the text differ (one bwt_query_all there serves both), at most either walk
+      uint64_t M[NCH], Dx[NCH];
+#pragma unroll
+      for (int c = 0; c < NCH; c++) { M[c] = E[c] | Eo[c] | QN[c]; Dx[c] = E[c] ^ Eo[c]; }
+      int phase = phase0, pos = pos0, end = end0;
+      bool fw = fw0, parted = false;
+      uint32_t walked = 0;
+      for (;;) {
+         for (;;) {
+            const int a = fw ? pos : end, b = fw ? end : pos;
+            const int e = first_event<NCH>(M, a, b, fw);
+            if (e < 0) { walked += (uint32_t)(b - a + 1); break; }
+            walked += (uint32_t)(fw ? e - pos : pos - e) + 1;
+            bool differ = test_bit<NCH>(Dx, e);
+            if (!differ) {
+               const int64_t ta = p0 + e, tb = p0_o + e;
+               const int la = (ta < 0 || ta >= A.ix.n) ? SYMS : A.text[ta], lb = (tb < 0 || tb >= A.ix.n) ? SYMS : A.text[tb];
+               differ = la != lb;
+            }
+            if (differ) { parted = true; break; }
+            if (e == end) break;
+            pos = e + (fw ? 1 : -1);
+         }
+         if (parted) break;
+         const uint2 rec = A.phase_rec[row * MAX_PHASES + phase];
+         if (rec.y >> 8) break;
+         phase = (int)(rec.x & 63);
+         fw = (rec.x >> META_FW) & 1;
+         end = (rec.x >> META_END) & 255;
+         pos = (int)(rec.y & 255);
+      }
+      shared = min(walked, min(steps, steps_o));
+   }
+   if (cand && q == 0) {
+      const bool f0 = key != ~0ull, f1 = key_o != ~0ull;
+      *reinterpret_cast<ulonglong2 *>(A.direct + 2 * i) = make_ulonglong2(f0 ? key : key_o, f0 && f1 ? key_o : ~0ull);
+      A.sizes[i] = (f0 ? 1 : 0) + (f1 ? 1 : 0);
+   }
+   steps -= shared;
    for (int o = 32; o > 0; o >>= 1) steps += (uint32_t)__shfl_xor((int)steps, o);
    if ((threadIdx.x & 63) == 0 && steps) atomicAdd(A.n_ext + (blockIdx.x & 63), (unsigned long long)steps);
 }
@@ -543,8 +643,15 @@ __global__ void __launch_bounds__(256) k_place(IndexDev ix, const Node *hits, in
 {
    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
    if (i >= n_hits) return;
-   const unsigned long long key = direct ? direct[i] : ~0ull;
-   if (key != ~0ull) { keys[hit_off[i]] = key; return; }
+   if (direct) {
+      const ulonglong2 k = *reinterpret_cast<const ulonglong2 *>(direct + 2 * i);
+      if (k.x != ~0ull) {
+         const int64_t off = hit_off[i];
+         keys[off] = k.x;
+         if (k.y != ~0ull) keys[off + 1] = k.y;
+         return;
+      }
+   }
    const int64_t sz = sizes[i];
    if (sz == 0) return;
    if (sz > PLACE_INLINE) {

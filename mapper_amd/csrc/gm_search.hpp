@@ -383,9 +383,10 @@ __global__ void __launch_bounds__(WG_THREADS) k_search(SearchArgs A)
       } else {
          have = false;
       }
-      // A node whose interval has shrunk to one suffix leaves the search: k_verify finishes it against the
-      // text (one suffix-array entry and a window of the text instead of one Occ line per letter).
-      const bool toverify = A.verify && have && !emit && sz == 1;
+      // A node whose interval has shrunk to one suffix (A.verify = 2: to one or two) leaves the search: k_verify
+      // finishes it against the text (a suffix-array entry and a window of the text per suffix instead of
+      // Occ lines per letter).
+      const bool toverify = A.verify && have && !emit && sz <= A.verify;
       if (__any(emit || toverify)) {
          Node out;
          out.w[0] = (uint32_t)fp; out.w[1] = (uint32_t)rp; out.w[2] = (uint32_t)sz;

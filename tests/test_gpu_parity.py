@@ -100,7 +100,7 @@ def test_verify_path_matches_reference_dump(workdir, name, tau):
     codes, offs = common.encode_reads(reads)
     ref = po.HitDump.load(os.path.join(common.GOLDEN, "%s.tau%d.bin" % (name, tau)))
     want_ext = orc.map_batch(codes, offs, tau, threads=2).n_ext
-    for verify in (1, 0):
+    for verify in (2, 1, 0):                     # nodes of one or two suffixes / of one suffix / none finished on the text
         ctx.set_option("verify", verify)
         b = ctx.upload(codes, offs)
         c = b.run(tau)
@@ -109,7 +109,7 @@ def test_verify_path_matches_reference_dump(workdir, name, tau):
         assert np.array_equal(h.status, ref.status)
         assert np.array_equal(h.located(), ref.located())
         assert h.n_ext == want_ext
-        assert (c["verify_steps"] > 0) == (verify == 1 and len(ref.located()) > 0)
+        assert (c["verify_steps"] > 0) == (verify >= 1 and len(ref.located()) > 0)
     ctx.close()
 
 
@@ -143,7 +143,7 @@ def test_verify_at_the_ends_of_the_text_and_at_separators(workdir):
     offs = np.concatenate(([0], np.cumsum([len(r) for r in reads]))).astype(np.int64)
     for tau in (0, 1, 2, 3):
         d = orc.map_batch(codes, offs, tau, threads=2)
-        for verify in (1, 0):
+        for verify in (2, 1, 0):
             ctx.set_option("verify", verify)
             h = ctx.map_batch(codes, offs, tau)
             assert np.array_equal(h.status, d.status)
