@@ -238,8 +238,13 @@ void          gpumap_batch_free(gpumap_batch *batch);
 int gpumap_mapper(const char *qfile, const gpumap_index *index, gpumap_ctx *ctx, int tau,
                   const char *out_path);
 
-/* Tuning knobs (0 keeps the default): waves per CU of the search kernel, reads admitted per
-** wave refill, per-wave spill capacity in nodes. */
+/* Options.  None changes a result, only where and how the work is done:
+**   "waves_per_cu"   persistent waves per CU of the search kernel (0 = as many as are resident)
+**   "spill_nodes"    per-wave spill capacity of the search deque, in nodes
+**   "pinned_results" 1 = gpumap_batch_fetch hands out slices of page-locked arenas of the context
+**   "jump_k"         letters of the jump table (0 = none, -1 = by the size of the text and the free memory)
+**   "verify"         0 = every step on the Occ table; 1 = nodes of one suffix are finished on the text;
+**                    2 = also nodes of two suffixes; -1 = by the size of the text (the default) */
 int gpumap_set_option(gpumap_ctx *ctx, const char *name, int64_t value);
 const char *gpumap_version(void);
 
