@@ -256,6 +256,23 @@ def test_repeat_rich_tau4_matches_oracle(workdir):
     ctx.close()
 
 
+@pytest.mark.parametrize("m,tau", [(100, 2), (150, 4), (64, 3), (33, 1)])
+def test_located_only_paths_match_oracle_on_repeats(workdir, m, tau):
+    """The path bench.py times (located hits only) on a repeat-rich text, where intervals of two suffixes are
+    common: both k_verify modes against the oracle, hits and count of extension steps."""
+    base, seqs = common.synth_index(workdir, "rep400k", 400_000, seed=31, n_seqs=2, repeat_rich=True)
+    codes, offs = synth.make_reads(seqs, 4000, m, min(tau, 4), seed=300 + m, n_frac=0.02)
+    ctx = ma.Context.from_files(base, 0)
+    d = po.Index(base).map_batch(codes.reshape(-1), offs, tau, threads=8)
+    for verify in (2, 1):
+        ctx.set_option("verify", verify)
+        h = ctx.map_batch(codes.reshape(-1), offs, tau)
+        assert np.array_equal(h.located(), d.located())
+        assert np.array_equal(h.read_first_loc, np.searchsorted(d.located()[:, 0], np.arange(len(offs))))
+        assert h.n_ext == d.n_ext
+    ctx.close()
+
+
 def test_spill_path_matches_oracle(small):
     """Reads with many N's blow up the frontier: forces the deque to spill to global memory."""
     base, ctx, orc = small
