@@ -256,12 +256,12 @@ def test_repeat_rich_tau4_matches_oracle(workdir):
     ctx.close()
 
 
-@pytest.mark.parametrize("m,tau", [(100, 2), (150, 4), (64, 3), (33, 1)])
+@pytest.mark.parametrize("m,tau", [(100, 2), (150, 4), (64, 3), (33, 1), (120, 6), (255, 7)])
 def test_located_only_paths_match_oracle_on_repeats(workdir, m, tau):
     """The path bench.py times (located hits only) on a repeat-rich text, where intervals of two suffixes are
     common: both k_verify modes against the oracle, hits and count of extension steps."""
     base, seqs = common.synth_index(workdir, "rep400k", 400_000, seed=31, n_seqs=2, repeat_rich=True)
-    codes, offs = synth.make_reads(seqs, 4000, m, min(tau, 4), seed=300 + m, n_frac=0.02)
+    codes, offs = synth.make_reads(seqs, 4000 if tau <= 4 else 300, m, min(tau, 4), seed=300 + m, n_frac=0.02)
     ctx = ma.Context.from_files(base, 0)
     d = po.Index(base).map_batch(codes.reshape(-1), offs, tau, threads=8)
     for verify in (2, 1):
@@ -270,6 +270,37 @@ def test_located_only_paths_match_oracle_on_repeats(workdir, m, tau):
         assert np.array_equal(h.located(), d.located())
         assert np.array_equal(h.read_first_loc, np.searchsorted(d.located()[:, 0], np.arange(len(offs))))
         assert h.n_ext == d.n_ext
+    ctx.close()
+
+
+@pytest.mark.parametrize("div", [0.0, 0.01, 0.05])
+def test_pairs_on_a_duplicated_text(workdir, div):
+    """Two copies of one sequence (the second with a fraction `div` of substitutions): nearly every node of the
+    search holds two suffixes for long stretches, then the copies part.  Both k_verify modes give the oracle's
+    located hits and its count of extension steps (steps the two walks share are counted once)."""
+    rng = np.random.default_rng(int(div * 1000) + 7)
+    a = rng.integers(0, 4, 120_000).astype(np.uint8)
+    b = a.copy()
+    hit = rng.random(len(b)) < div
+    b[hit] = (b[hit] + rng.integers(1, 4, int(hit.sum()))) % 4
+    b[5000:5040] = 4                                   # an N run in one copy only
+    seqs = [a, b]
+    base = os.path.join(workdir, "dup_%d" % int(div * 1000))
+    ma.HostIndex.build_codes(seqs, ["a", "b"], base).close()
+    codes, offs = synth.make_reads(seqs, 3000, 100, 2, seed=int(div * 1000) + 9, n_frac=0.02)
+    ctx = ma.Context.from_files(base, 0)
+    orc = po.Index(base)
+    for tau in (2, 3):
+        d = orc.map_batch(codes.reshape(-1), offs, tau, threads=8)
+        for verify in (2, 1, 0):
+            ctx.set_option("verify", verify)
+            b_ = ctx.upload(codes.reshape(-1), offs)
+            c = b_.run(tau)
+            h = b_.fetch()
+            b_.close()
+            assert np.array_equal(h.located(), d.located()), (tau, verify)
+            assert h.n_ext == d.n_ext, (tau, verify)
+            assert (c["verify_steps"] > 0) == (verify >= 1)
     ctx.close()
 
 
