@@ -18,7 +18,7 @@ struct gpumap_batch {
    int64_t n_reads = 0;
    int stride = 0;
    std::vector<int64_t> offsets;     // host copy (n_reads + 1)
-   DevBuf reads, reads4, read_len, len_row, phases, phase_rec, phase_lo, status;
+   DevBuf reads, reads4, read_len, len_row, row_len, phases, phase_rec, phase_lo, status;
    DevBuf up_src, up_off;            // staging of the upload (kept by a batch that is refilled)
    DevBuf hits, hit_sizes, hit_off, direct, longer, keys, keys_alt, read_cnt, read_first;
    DevBuf loc_read, loc_pos, loc_fwd, loc_seq, loc_seqpos, loc_strand, loc_score;
@@ -32,7 +32,7 @@ struct gpumap_batch {
    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};      // [4]: between k_search and k_verify
    void release()
    {
-      for (DevBuf *b : {&up_src, &up_off, &reads, &reads4, &read_len, &len_row, &phases, &phase_rec, &phase_lo, &status, &hits, &hit_sizes, &hit_off, &direct, &longer, &keys, &keys_alt,
+      for (DevBuf *b : {&up_src, &up_off, &reads, &reads4, &read_len, &len_row, &row_len, &phases, &phase_rec, &phase_lo, &status, &hits, &hit_sizes, &hit_off, &direct, &longer, &keys, &keys_alt,
                         &read_cnt, &read_first, &loc_read, &loc_pos, &loc_fwd, &loc_seq, &loc_seqpos, &loc_strand,
                         &loc_score, &hkeys, &hkeys_alt, &hidx, &hidx_alt, &hit_read, &hit_fp, &hit_rp, &hit_sz,
                         &hit_dp, &hit_score, &hit_align})
@@ -528,6 +528,7 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
       std::vector<uint8_t> len_row(MAX_READ + 1, 0xff);
       std::vector<uint32_t> phases, phase_rec;
       std::vector<uint8_t> phase_lo;
+      std::vector<uint16_t> row_len;
       int rows = 0;
       for (int m = 1; m <= MAX_READ; m++) {
          if (!b->length_seen[m]) continue;
@@ -538,6 +539,7 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
          if (!build_phase_table(m, tau, tab, lo_tab)) continue;        // the reference returns -1 for this length
          GM_FAIL_IF(rows >= 255, "too many distinct read lengths.");
          len_row[m] = (uint8_t)rows++;
+         row_len.push_back((uint16_t)m);
          phases.insert(phases.end(), tab, tab + MAX_PHASES);
          phase_lo.insert(phase_lo.end(), lo_tab, lo_tab + MAX_PHASES);
          for (int p = 0; p < MAX_PHASES; p++) {
@@ -547,6 +549,7 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
          }
       }
       if (phases.empty()) { phases.assign(MAX_PHASES, 0); phase_rec.assign(2 * MAX_PHASES, 0); phase_lo.assign(MAX_PHASES, 0); }
+      if (row_len.empty()) row_len.push_back(0);
       HIP_TRY(b->len_row.ensure(MAX_READ + 1));
       HIP_TRY(b->phases.ensure(4 * phases.size()));
       HIP_TRY(b->phase_rec.ensure(4 * phase_rec.size()));
@@ -554,6 +557,8 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
       HIP_TRY(b->phase_lo.ensure(phase_lo.size()));
       HIP_TRY(hipMemcpyAsync(b->phase_lo.p, phase_lo.data(), phase_lo.size(), hipMemcpyHostToDevice, st));
       HIP_TRY(hipMemcpyAsync(b->len_row.p, len_row.data(), MAX_READ + 1, hipMemcpyHostToDevice, st));
+      HIP_TRY(b->row_len.ensure(2 * row_len.size()));
+      HIP_TRY(hipMemcpyAsync(b->row_len.p, row_len.data(), 2 * row_len.size(), hipMemcpyHostToDevice, st));
       HIP_TRY(hipMemcpyAsync(b->phases.p, phases.data(), 4 * phases.size(), hipMemcpyHostToDevice, st));
       if (R > 0) {
          hipLaunchKernelGGL(k_status, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, st, b->read_len.as<const uint16_t>(),
@@ -637,7 +642,7 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
          VerifyArgs V;
          V.ix = ctx->ix; V.text = (const uint8_t *)ctx->d_text; V.text4 = (const uint8_t *)ctx->d_text4;
          V.reads4 = b->reads4.as<const uint8_t>();
-         V.reads = b->reads.as<const uint8_t>(); V.read_len = b->read_len.as<const uint16_t>();
+         V.reads = b->reads.as<const uint8_t>(); V.row_len = b->row_len.as<const uint16_t>();
          V.phase_rec = b->phase_rec.as<const uint2>(); V.phase_lo = b->phase_lo.as<const uint8_t>();
          V.list = b->hits.as<const Node>(); V.n_list = H; V.stride = b->stride; V.n_ext = cnt + 8;
          V.direct = b->direct.as<unsigned long long>(); V.sizes = b->hit_sizes.as<int64_t>();

@@ -274,7 +274,7 @@ struct VerifyArgs {
    const uint8_t  *text4;       // the same, two symbols per byte (k_pack_nibbles), 32 bytes of padding behind
    const uint8_t  *reads;
    const uint8_t  *reads4;      // [n_reads][stride / 2] the rows of `reads`, two symbols per byte
-   const uint16_t *read_len;
+   const uint16_t *row_len;     // [rows] the read length of each row of the phase tables (one row per length)
    const uint2    *phase_rec;   // [rows][MAX_PHASES]
    const uint8_t  *phase_lo;    // [rows][MAX_PHASES]
    const Node *list;
@@ -374,7 +374,7 @@ __global__ void __launch_bounds__(256) k_verify(VerifyArgs A)
       uint32_t meta = nd.w[5] & ~(1u << META_CAND);
       read = nd.w[4];
       row = (int)(nd.w[7] >> 24);
-      m = A.read_len[read];
+      m = A.row_len[row];
       int phase = (int)(meta & 63);
       bool fw = (meta >> META_FW) & 1, dash = (meta >> META_DASH) & 1;
       int end = (meta >> META_END) & 255, tau = (meta >> META_TAU) & 7, diff = (meta >> META_DIFF) & 7;
