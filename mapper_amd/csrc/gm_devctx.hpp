@@ -76,7 +76,7 @@ struct gpumap_ctx {
    bool owns_text = true;
    // jump table of the leaf phases (k_build_jump): 4^jump_k entries of 16 bytes, nullptr = off
    void *d_jump = nullptr;
-   void *d_text4 = nullptr;       // the text, two symbols per byte (k_pack_nibbles), built with the jump table when the text is in HBM
+   void *d_text4 = nullptr;       // the text as bit planes (k_pack_planes), built with the jump table when the text is in HBM
    int jump_k = 0;
    // launch shape
    int cu_count = 256;

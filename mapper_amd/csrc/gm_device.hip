@@ -16,7 +16,7 @@ using namespace gm;
 struct gpumap_batch {
    gpumap_ctx *ctx = nullptr;
    int64_t n_reads = 0;
-   int stride = 0;
+   int stride = 0, maxlen = 1;
    std::vector<int64_t> offsets;     // host copy (n_reads + 1)
    DevBuf reads, reads4, read_len, len_row, row_len, phases, phase_rec, phase_lo, status;
    DevBuf up_src, up_off;            // staging of the upload (kept by a batch that is refilled)
@@ -86,11 +86,11 @@ int gm_ctx_build_jump(gpumap_ctx *ctx, int k)
 {
    if (ctx->d_jump) { HIP_TRY(hipFree(ctx->d_jump)); ctx->d_jump = nullptr; ctx->jump_k = 0; }
    if (ctx->d_text != nullptr && ctx->d_text4 == nullptr) {
-      // what k_verify compares windows of: 8 symbols per word, 32 bytes of separators behind the end
-      const int64_t words = cdiv(ctx->ix.n, 8) + 8;
-      HIP_TRY(hipMalloc(&ctx->d_text4, 4 * (size_t)words));
-      hipLaunchKernelGGL(k_pack_nibbles, dim3((unsigned)std::min<int64_t>(cdiv(words, 256), 1 << 20)), dim3(256), 0, ctx->stream,
-                         (const uint8_t *)ctx->d_text, ctx->ix.n, (uint8_t)SYMS, (uint32_t *)ctx->d_text4, words);
+      // what k_verify compares windows of: bit planes in units of 128 symbols, four units of separators behind the end
+      const int64_t units = cdiv(ctx->ix.n, 128) + 4, groups = 4 * units;
+      HIP_TRY(hipMalloc(&ctx->d_text4, 48 * (size_t)units));
+      hipLaunchKernelGGL(k_pack_planes, dim3((unsigned)std::min<int64_t>(cdiv(groups, 256), 1 << 20)), dim3(256), 0, ctx->stream,
+                         (const uint8_t *)ctx->d_text, ctx->ix.n, (uint8_t)SYMS, (uint32_t *)ctx->d_text4, groups);
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipStreamSynchronize(ctx->stream));
    }
@@ -446,11 +446,12 @@ static int batch_fill(gpumap_ctx *ctx, gpumap_batch *b, const uint8_t *src, cons
          GM_FAIL_IF(len < 0, "offsets must not decrease.");
          if (len <= MAX_READ) { b->length_seen[len] = true; maxlen = std::max(maxlen, len); }
       }
-      b->stride = (int)((maxlen + 31) & ~(int64_t)31);      // packed rows (two symbols per byte) are read as 16-byte units
+      b->stride = (int)((maxlen + 127) & ~(int64_t)127);    // the rows as bit planes come in units of 128 symbols
+      b->maxlen = (int)maxlen;
       int64_t total = offsets[n_reads] - offsets[0];
       GM_FAIL_IF(total > 0 && src == nullptr, "argument 'codes' is NULL.");
       HIP_TRY(b->reads.ensure((size_t)std::max<int64_t>(1, n_reads) * b->stride));
-      HIP_TRY(b->reads4.ensure((size_t)std::max<int64_t>(1, n_reads) * (b->stride / 2)));
+      HIP_TRY(b->reads4.ensure((size_t)std::max<int64_t>(1, n_reads) * (size_t)(48 * (b->stride / 128))));
       HIP_TRY(b->read_len.ensure(2 * (size_t)std::max<int64_t>(1, n_reads)));
       HIP_TRY(b->status.ensure(8 * (size_t)std::max<int64_t>(1, n_reads)));
       for (auto &e : b->ev) if (!e) HIP_TRY(hipEventCreate(&e));
@@ -466,9 +467,9 @@ static int batch_fill(gpumap_ctx *ctx, gpumap_batch *b, const uint8_t *src, cons
                             b->up_src.as<const uint8_t>(), b->up_off.as<const int64_t>(), n_reads, b->stride,
                             is_text ? (const uint8_t *)ctx->d_sym_table : (const uint8_t *)nullptr,
                             b->reads.as<uint8_t>(), b->read_len.as<uint16_t>(), (uint8_t *)nullptr);
-         const int64_t words = n_reads * (b->stride / 8);
-         hipLaunchKernelGGL(k_pack_nibbles, dim3((unsigned)std::min<int64_t>(cdiv(words, 256), 1 << 20)), dim3(256), 0, ctx->stream,
-                            b->reads.as<const uint8_t>(), n_reads * b->stride, (uint8_t)0xff, b->reads4.as<uint32_t>(), words);
+         const int64_t groups = n_reads * (b->stride / 32);
+         hipLaunchKernelGGL(k_pack_planes, dim3((unsigned)std::min<int64_t>(cdiv(groups, 256), 1 << 20)), dim3(256), 0, ctx->stream,
+                            b->reads.as<const uint8_t>(), n_reads * b->stride, (uint8_t)0xff, b->reads4.as<uint32_t>(), groups);
          HIP_TRY(hipGetLastError());
          HIP_TRY(hipStreamSynchronize(ctx->stream));
       }
@@ -652,7 +653,7 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
          const dim3 vgrid((unsigned)cdiv((pairs ? 2 : 1) * V.n_list, vbd));
 #define GM_VERIFY(N) do { if (pairs) hipLaunchKernelGGL((k_verify<N, true>), vgrid, dim3(vbd), 0, st, V); \
                           else hipLaunchKernelGGL((k_verify<N, false>), vgrid, dim3(vbd), 0, st, V); } while (0)
-         switch (cdiv(b->stride, 64)) {                                 // 64-letter pieces of the longest read
+         switch (cdiv(b->maxlen, 64)) {                                 // 64-letter pieces of the longest read
             case 1:  GM_VERIFY(1); break;
             case 2:  GM_VERIFY(2); break;
             case 3:  GM_VERIFY(3); break;

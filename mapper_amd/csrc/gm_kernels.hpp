@@ -198,26 +198,36 @@ __global__ void k_encode(const uint8_t *src, const int64_t *offsets, int64_t n_r
    }
 }
 
-// Two symbols per byte (the first in the low half) for the windows k_verify compares: half the lines
-// per window.  src holds n_src bytes (codes 0..5, or 0xff behind the end of a read); what lies behind is
-// written as `fill`.  One thread per 8 symbols.
-__global__ void k_pack_nibbles(const uint8_t *src, int64_t n_src, uint8_t fill, uint32_t *dst, int64_t n_words)
+// Bit planes for the windows k_verify compares: a unit of 128 symbols is 48 bytes, bit p of the symbols'
+// codes in its p-th 16 bytes (symbol k of the unit in word k / 32, bit k % 32), so that the places where
+// a window and a query differ come out of XORs of whole words, in the order of the letters.  src holds
+// n_src bytes (codes 0..5, or 0xff behind the end of a read); what lies behind is written as `fill`.
+// One thread per 32 symbols.
+__global__ void k_pack_planes(const uint8_t *src, int64_t n_src, uint8_t fill, uint32_t *dst, int64_t n_groups)
 {
-   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_words; i += (int64_t)gridDim.x * blockDim.x) {
-      uint32_t a, b;
-      if (8 * i + 8 <= n_src) {
-         const uint2 v = *reinterpret_cast<const uint2 *>(src + 8 * i);
-         a = v.x; b = v.y;
+   for (int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; g < n_groups; g += (int64_t)gridDim.x * blockDim.x) {
+      uint32_t x[8];
+      if (32 * g + 32 <= n_src) {
+         const uint4 v0 = *reinterpret_cast<const uint4 *>(src + 32 * g), v1 = *reinterpret_cast<const uint4 *>(src + 32 * g + 16);
+         x[0] = v0.x; x[1] = v0.y; x[2] = v0.z; x[3] = v0.w; x[4] = v1.x; x[5] = v1.y; x[6] = v1.z; x[7] = v1.w;
       } else {
-         a = b = 0;
-         for (int k = 0; k < 8; k++) {
-            const uint32_t c = 8 * i + k < n_src ? src[8 * i + k] : fill;
-            if (k < 4) a |= c << (8 * k); else b |= c << (8 * (k - 4));
+#pragma unroll
+         for (int j = 0; j < 8; j++) {
+            x[j] = 0;
+            for (int k = 0; k < 4; k++) {
+               const int64_t at = 32 * g + 4 * j + k;
+               x[j] |= (uint32_t)(at < n_src ? src[at] : fill) << (8 * k);
+            }
          }
       }
-      const uint32_t pa = (a & 0xfu) | ((a >> 4) & 0xf0u) | ((a >> 8) & 0xf00u) | ((a >> 12) & 0xf000u);
-      const uint32_t pb = (b & 0xfu) | ((b >> 4) & 0xf0u) | ((b >> 8) & 0xf00u) | ((b >> 12) & 0xf000u);
-      dst[i] = pa | (pb << 16);
+      uint32_t pl[3] = {0, 0, 0};
+#pragma unroll
+      for (int j = 0; j < 8; j++)
+#pragma unroll
+         for (int p = 0; p < 3; p++)       // bits p of four bytes -> four adjacent bits (the products' terms do not meet)
+            pl[p] |= (((((x[j] >> p) & 0x01010101u) * 0x01020408u) >> 24) & 0xfu) << (4 * j);
+      uint32_t *o = dst + (g >> 2) * 12 + (g & 3);
+      o[0] = pl[0]; o[4] = pl[1]; o[8] = pl[2];
    }
 }
 
@@ -271,9 +281,9 @@ struct SearchArgs {
 struct VerifyArgs {
    IndexDev ix;
    const uint8_t  *text;        // [n] codes 0..5
-   const uint8_t  *text4;       // the same, two symbols per byte (k_pack_nibbles), 32 bytes of padding behind
+   const uint8_t  *text4;       // the same as bit planes (k_pack_planes), four units of separators behind
    const uint8_t  *reads;
-   const uint8_t  *reads4;      // [n_reads][stride / 2] the rows of `reads`, two symbols per byte
+   const uint8_t  *reads4;      // [n_reads][stride / 128] units: the rows of `reads` as bit planes (stride % 128 == 0)
    const uint16_t *row_len;     // [rows] the read length of each row of the phase tables (one row per length)
    const uint2    *phase_rec;   // [rows][MAX_PHASES]
    const uint8_t  *phase_lo;    // [rows][MAX_PHASES]
@@ -286,12 +296,13 @@ struct VerifyArgs {
    int key_shift;                  // key = read << key_shift | text position << 4 | score (as k_place)
 };
 
-// The query row and the text window of a candidate are read as 16-byte units of 32 symbols (four bits
-// per symbol; every lane of a load touches a line of its own, so the number of load instructions and of
-// lines is what the memory path pays for) and compared a word at a time in registers; what is kept is
-// one bit per letter: E = the letter costs a mismatch (text and query differ and the query letter is
-// not N), S = the text holds a separator there.  The walk then goes from event to event with
-// ffs / clz on those bits: plain matches between events are counted, not visited.
+// The query row and the text window of a candidate are read as bit planes (k_pack_planes: 16 bytes per
+// plane and 128 symbols; every lane of a load touches a line of its own, so the number of load
+// instructions and of lines is what the memory path pays for), the window's words are shifted to the
+// query's with v_alignbit and the planes XORed; what is kept is one bit per letter: E = the letter costs a
+// mismatch (text and query differ and the query letter is not N), S = the text holds a separator
+// there.  The walk then goes from event to event with ffs / clz on those bits: plain matches between
+// events are counted, not visited.
 // NCH = 64-letter pieces of the longest read of the batch.
 __device__ __forceinline__ uint32_t sel4w(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t j)
 {
@@ -382,55 +393,49 @@ __global__ void __launch_bounds__(256) k_verify(VerifyArgs A)
       phase0 = phase; pos0 = pos; end0 = end; fw0 = fw;
       const int lo = fw ? A.phase_lo[row * MAX_PHASES + phase] : pos + 1;      // lowest query position matched so far
       p0 = sa_entry(A.ix.sa, A.ix.sar_bits, fp) - lo;                            // text position of query position 0
-      const int nq = (m + 31) >> 5;                                            // 32-letter units of the query row
-      // the window inside the text (the packed text has 32 bytes of padding: whole units can be read)
+      const int nq = (m + 31) >> 5;                                            // 32-letter words of the query row
+      // the window inside the text (the planes have four units of padding: whole units can be read)
       bool fast = p0 >= 0 && p0 + m <= A.ix.n;
       if (fast) {
-         const uint4 *q16 = reinterpret_cast<const uint4 *>(A.reads4 + (size_t)read * (size_t)(A.stride >> 1));
-         const uint4 *t16 = reinterpret_cast<const uint4 *>(A.text4) + (p0 >> 5);
-         const uint32_t ws = (uint32_t)(p0 >> 3) & 3, bs = 4 * ((uint32_t)p0 & 7);   // word and bit offset of the window in its unit
-         uint32_t sepacc = 0;
-         uint4 carry = t16[0];
+         constexpr int NU = NCH <= 2 ? 2 : 3;        // units of the text a window can touch
+         constexpr int NW = 2 * NCH;                 // 32-letter words of the masks
+         constexpr int NQ = (NCH + 1) / 2;           // units of a query row
+         const uint4 *q16 = reinterpret_cast<const uint4 *>(A.reads4) + (size_t)read * (size_t)(3 * (A.stride >> 7));
+         const uint4 *t16 = reinterpret_cast<const uint4 *>(A.text4) + 3 * (p0 >> 7);
+         const uint32_t ws = ((uint32_t)p0 >> 5) & 3, bs = (uint32_t)p0 & 31;        // word and bit offset of the window in its unit
+         uint32_t tw[3][NW], qw[3][4 * NQ];
+#pragma unroll
+         for (int p = 0; p < 3; p++) {
+            uint32_t T[4 * NU];
+#pragma unroll
+            for (int k = 0; k < NU; k++) {
+               const uint4 v = t16[3 * k + p];
+               T[4 * k] = v.x; T[4 * k + 1] = v.y; T[4 * k + 2] = v.z; T[4 * k + 3] = v.w;
+            }
+#pragma unroll
+            for (int k = 0; k < NQ; k++) {
+               const uint4 v = q16[3 * k + p];
+               qw[p][4 * k] = v.x; qw[p][4 * k + 1] = v.y; qw[p][4 * k + 2] = v.z; qw[p][4 * k + 3] = v.w;
+            }
+            uint32_t G[NW + 1];
+#pragma unroll
+            for (int j = 0; j < NW + 1; j++) G[j] = sel4w(T[j], T[j + 1], T[j + 2], T[j + 3], ws);
+#pragma unroll
+            for (int w = 0; w < NW; w++) tw[p][w] = __builtin_amdgcn_alignbit(G[w + 1], G[w], bs);
+         }
+         uint32_t sepacc = 0, Ew[NW];
+#pragma unroll
+         for (int w = 0; w < NW; w++) {
+            // plane 2 is "not a base": a text N against a base costs one, a query N (and what lies behind the read) is free
+            Ew[w] = ((tw[0][w] ^ qw[0][w]) | (tw[1][w] ^ qw[1][w]) | (tw[2][w] ^ qw[2][w])) & ~qw[2][w];
+            if (w < nq) sepacc |= tw[2][w] & tw[0][w];                                 // code 5: a separator
+         }
 #pragma unroll
          for (int c = 0; c < NCH; c++) {
-            if (2 * c < nq) {
-               uint32_t T[12], Q[8];
-               T[0] = carry.x; T[1] = carry.y; T[2] = carry.z; T[3] = carry.w;
-#pragma unroll
-               for (int j = 0; j < 2; j++) {
-                  uint4 tv = make_uint4(0, 0, 0, 0), qv = make_uint4(0, 0, 0, 0);
-                  if (2 * c + j < nq) { tv = t16[2 * c + j + 1]; qv = q16[2 * c + j]; }
-                  T[4 + 4 * j] = tv.x; T[5 + 4 * j] = tv.y; T[6 + 4 * j] = tv.z; T[7 + 4 * j] = tv.w;
-                  Q[4 * j] = qv.x; Q[4 * j + 1] = qv.y; Q[4 * j + 2] = qv.z; Q[4 * j + 3] = qv.w;
-               }
-               carry = make_uint4(T[8], T[9], T[10], T[11]);
-               uint32_t X[9];
-#pragma unroll
-               for (int j = 0; j < 9; j++) X[j] = sel4w(T[j], T[j + 1], T[j + 2], T[j + 3], ws);
-               uint32_t half[2] = {0, 0}, nhalf[2] = {0, 0};
-#pragma unroll
-               for (int w = 0; w < 8; w++) {
-                  const uint32_t tw = __builtin_amdgcn_alignbit(X[w + 1], X[w], bs), qw = Q[w];
-                  const uint32_t x = qw ^ tw;
-                  uint32_t nn = (qw >> 2) & 0x11111111u;                                      // query N
-                  uint32_t d = (x | (x >> 1) | (x >> 2)) & ~nn & 0x11111111u;                // letters that cost a mismatch
-                  sepacc |= (tw >> 2) & tw;                                                  // bit 0 of a symbol: code 5
-                  d = (d | (d >> 3)) & 0x03030303u;                                          // bits 0,4,..,28 -> 0..7
-                  d = (d | (d >> 6)) & 0x000f000fu;
-                  d = (d | (d >> 12)) & 0xffu;
-                  half[w >> 2] |= d << (8 * (w & 3));
-                  if (pair) {                                                                // (needed to tell where the pair parts)
-                     nn = (nn | (nn >> 3)) & 0x03030303u;
-                     nn = (nn | (nn >> 6)) & 0x000f000fu;
-                     nn = (nn | (nn >> 12)) & 0xffu;
-                     nhalf[w >> 2] |= nn << (8 * (w & 3));
-                  }
-               }
-               E[c] = (uint64_t)half[0] | ((uint64_t)half[1] << 32);
-               QN[c] = (uint64_t)nhalf[0] | ((uint64_t)nhalf[1] << 32);
-            }
+            E[c] = (uint64_t)Ew[2 * c] | ((uint64_t)Ew[2 * c + 1] << 32);
+            QN[c] = (uint64_t)qw[2][2 * c] | ((uint64_t)qw[2][2 * c + 1] << 32);
          }
-         if (sepacc & 0x11111111u) fast = false;           // a separator in (or just behind) the window
+         if (sepacc) fast = false;                          // a separator in (or just behind) the window
       }
       if (!fast) {
          // a window over an end of the text or over a separator: letter by letter, separators outside the text
