@@ -130,7 +130,8 @@ int main(int argc, char **argv)
    hipDeviceProp_t prop;
    CK(hipGetDeviceProperties(&prop, 0));
    int cus = prop.multiProcessorCount;
-   uint64_t max_bytes = (uint64_t)4 << 30;
+   const int big_gib = argc > 2 ? atoi(argv[2]) : 0;      // second argument: also footprints up to that many GiB (TLB reach)
+   uint64_t max_bytes = (uint64_t)(big_gib > 4 ? big_gib : 4) << 30;
    uint4 *buf; uint32_t *sink;
    CK(hipMalloc(&buf, max_bytes));
    CK(hipMalloc(&sink, 64));
@@ -147,5 +148,10 @@ int main(int argc, char **argv)
          run<3>("lane64", buf, f, w, steps, cus, sink, 64, 1, 1);
          run<4>("lane16", buf, f, w, steps, cus, sink, 16, 1, 1);
       }
+   for (uint64_t f = (uint64_t)8 << 30; f <= max_bytes; f <<= 1) {      // beyond 4 GiB: 32 waves per CU only
+      run<0>("quad64", buf, f, 32, steps, cus, sink, 64, 4, 1);
+      run<3>("lane64", buf, f, 32, steps, cus, sink, 64, 1, 1);
+      run<4>("lane16", buf, f, 32, steps, cus, sink, 16, 1, 1);
+   }
    return 0;
 }
