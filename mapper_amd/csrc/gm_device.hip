@@ -86,7 +86,7 @@ int gm_ctx_build_jump(gpumap_ctx *ctx, int k)
 {
    if (ctx->d_jump) { HIP_TRY(hipFree(ctx->d_jump)); ctx->d_jump = nullptr; ctx->jump_k = 0; }
    if (ctx->d_text != nullptr && ctx->d_text4 == nullptr) {
-      // what k_verify compares windows of: bit planes in units of 128 symbols, four units of separators behind the end
+      // what k_verify compares windows of: bit planes, 12 bytes per 32 symbols, 512 symbols of separators behind the end
       const int64_t units = cdiv(ctx->ix.n, 128) + 4, groups = 4 * units;
       HIP_TRY(hipMalloc(&ctx->d_text4, 48 * (size_t)units));
       hipLaunchKernelGGL(k_pack_planes, dim3((unsigned)std::min<int64_t>(cdiv(groups, 256), 1 << 20)), dim3(256), 0, ctx->stream,
@@ -451,7 +451,7 @@ static int batch_fill(gpumap_ctx *ctx, gpumap_batch *b, const uint8_t *src, cons
       int64_t total = offsets[n_reads] - offsets[0];
       GM_FAIL_IF(total > 0 && src == nullptr, "argument 'codes' is NULL.");
       HIP_TRY(b->reads.ensure((size_t)std::max<int64_t>(1, n_reads) * b->stride));
-      HIP_TRY(b->reads4.ensure((size_t)std::max<int64_t>(1, n_reads) * (size_t)(48 * (b->stride / 128))));
+      HIP_TRY(b->reads4.ensure((size_t)std::max<int64_t>(1, n_reads) * (size_t)(12 * (b->stride / 32))));
       HIP_TRY(b->read_len.ensure(2 * (size_t)std::max<int64_t>(1, n_reads)));
       HIP_TRY(b->status.ensure(8 * (size_t)std::max<int64_t>(1, n_reads)));
       for (auto &e : b->ev) if (!e) HIP_TRY(hipEventCreate(&e));

@@ -198,11 +198,11 @@ __global__ void k_encode(const uint8_t *src, const int64_t *offsets, int64_t n_r
    }
 }
 
-// Bit planes for the windows k_verify compares: a unit of 128 symbols is 48 bytes, bit p of the symbols'
-// codes in its p-th 16 bytes (symbol k of the unit in word k / 32, bit k % 32), so that the places where
-// a window and a query differ come out of XORs of whole words, in the order of the letters.  src holds
-// n_src bytes (codes 0..5, or 0xff behind the end of a read); what lies behind is written as `fill`.
-// One thread per 32 symbols.
+// Bit planes for the windows k_verify compares: 32 symbols are 12 bytes, word p = bit p of the symbols'
+// codes (symbol k in bit k), so that the places where a window and a query differ come out of XORs of
+// whole words, in the order of the letters, and a window is one run of 12 bytes per 32 letters.  src
+// holds n_src bytes (codes 0..5, or 0xff behind the end of a read); what lies behind is written as
+// `fill`.  One thread per 32 symbols.
 __global__ void k_pack_planes(const uint8_t *src, int64_t n_src, uint8_t fill, uint32_t *dst, int64_t n_groups)
 {
    for (int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; g < n_groups; g += (int64_t)gridDim.x * blockDim.x) {
@@ -226,8 +226,8 @@ __global__ void k_pack_planes(const uint8_t *src, int64_t n_src, uint8_t fill, u
 #pragma unroll
          for (int p = 0; p < 3; p++)       // bits p of four bytes -> four adjacent bits (the products' terms do not meet)
             pl[p] |= (((((x[j] >> p) & 0x01010101u) * 0x01020408u) >> 24) & 0xfu) << (4 * j);
-      uint32_t *o = dst + (g >> 2) * 12 + (g & 3);
-      o[0] = pl[0]; o[4] = pl[1]; o[8] = pl[2];
+      uint32_t *o = dst + 3 * g;
+      o[0] = pl[0]; o[1] = pl[1]; o[2] = pl[2];
    }
 }
 
@@ -281,9 +281,9 @@ struct SearchArgs {
 struct VerifyArgs {
    IndexDev ix;
    const uint8_t  *text;        // [n] codes 0..5
-   const uint8_t  *text4;       // the same as bit planes (k_pack_planes), four units of separators behind
+   const uint8_t  *text4;       // the same as bit planes (k_pack_planes), 512 symbols of separators behind
    const uint8_t  *reads;
-   const uint8_t  *reads4;      // [n_reads][stride / 128] units: the rows of `reads` as bit planes (stride % 128 == 0)
+   const uint8_t  *reads4;      // [n_reads][3 * stride / 32] words: the rows of `reads` as bit planes (stride % 128 == 0)
    const uint16_t *row_len;     // [rows] the read length of each row of the phase tables (one row per length)
    const uint2    *phase_rec;   // [rows][MAX_PHASES]
    const uint8_t  *phase_lo;    // [rows][MAX_PHASES]
@@ -304,6 +304,8 @@ struct VerifyArgs {
 // there.  The walk then goes from event to event with ffs / clz on those bits: plain matches between
 // events are counted, not visited.
 // NCH = 64-letter pieces of the longest read of the batch.
+struct __attribute__((packed, aligned(4))) u4x { uint32_t x, y, z, w; };      // 16 bytes at any word
+
 __device__ __forceinline__ uint32_t sel4w(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t j)
 {
    uint32_t r = a;
@@ -394,35 +396,34 @@ __global__ void __launch_bounds__(256) k_verify(VerifyArgs A)
       const int lo = fw ? A.phase_lo[row * MAX_PHASES + phase] : pos + 1;      // lowest query position matched so far
       p0 = sa_entry(A.ix.sa, A.ix.sar_bits, fp) - lo;                            // text position of query position 0
       const int nq = (m + 31) >> 5;                                            // 32-letter words of the query row
-      // the window inside the text (the planes have four units of padding: whole units can be read)
+      // the window inside the text (the planes have 512 symbols of padding: whole loads can be made)
       bool fast = p0 >= 0 && p0 + m <= A.ix.n;
       if (fast) {
-         constexpr int NU = NCH <= 2 ? 2 : 3;        // units of the text a window can touch
          constexpr int NW = 2 * NCH;                 // 32-letter words of the masks
-         constexpr int NQ = (NCH + 1) / 2;           // units of a query row
-         const uint4 *q16 = reinterpret_cast<const uint4 *>(A.reads4) + (size_t)read * (size_t)(3 * (A.stride >> 7));
-         const uint4 *t16 = reinterpret_cast<const uint4 *>(A.text4) + 3 * (p0 >> 7);
-         const uint32_t ws = ((uint32_t)p0 >> 5) & 3, bs = (uint32_t)p0 & 31;        // word and bit offset of the window in its unit
-         uint32_t tw[3][NW], qw[3][4 * NQ];
+         constexpr int NT = (3 * (NW + 1) + 3) / 4;  // 16-byte loads of the window: NW + 1 runs of 12 bytes
+         constexpr int NQ = (3 * NW + 3) / 4;        // 16-byte loads of the query row
+         const uint4 *q16 = reinterpret_cast<const uint4 *>(A.reads4 + (size_t)read * (size_t)(3 * (A.stride >> 3)));
+         const u4x *t16 = reinterpret_cast<const u4x *>(A.text4 + 12 * (p0 >> 5));      // (aligned to 4 bytes)
+         const uint32_t bs = (uint32_t)p0 & 31;      // bit offset of the window in its first words
+         uint32_t T[4 * NT], Q[4 * NQ];
 #pragma unroll
-         for (int p = 0; p < 3; p++) {
-            uint32_t T[4 * NU];
-#pragma unroll
-            for (int k = 0; k < NU; k++) {
-               const uint4 v = t16[3 * k + p];
-               T[4 * k] = v.x; T[4 * k + 1] = v.y; T[4 * k + 2] = v.z; T[4 * k + 3] = v.w;
-            }
-#pragma unroll
-            for (int k = 0; k < NQ; k++) {
-               const uint4 v = q16[3 * k + p];
-               qw[p][4 * k] = v.x; qw[p][4 * k + 1] = v.y; qw[p][4 * k + 2] = v.z; qw[p][4 * k + 3] = v.w;
-            }
-            uint32_t G[NW + 1];
-#pragma unroll
-            for (int j = 0; j < NW + 1; j++) G[j] = sel4w(T[j], T[j + 1], T[j + 2], T[j + 3], ws);
-#pragma unroll
-            for (int w = 0; w < NW; w++) tw[p][w] = __builtin_amdgcn_alignbit(G[w + 1], G[w], bs);
+         for (int k = 0; k < NT; k++) {
+            const u4x v = t16[k];
+            T[4 * k] = v.x; T[4 * k + 1] = v.y; T[4 * k + 2] = v.z; T[4 * k + 3] = v.w;
          }
+#pragma unroll
+         for (int k = 0; k < NQ; k++) {
+            const uint4 v = q16[k];
+            Q[4 * k] = v.x; Q[4 * k + 1] = v.y; Q[4 * k + 2] = v.z; Q[4 * k + 3] = v.w;
+         }
+         uint32_t tw[3][NW], qw[3][NW];
+#pragma unroll
+         for (int p = 0; p < 3; p++)
+#pragma unroll
+            for (int w = 0; w < NW; w++) {
+               tw[p][w] = __builtin_amdgcn_alignbit(T[3 * (w + 1) + p], T[3 * w + p], bs);
+               qw[p][w] = Q[3 * w + p];
+            }
          uint32_t sepacc = 0, Ew[NW];
 #pragma unroll
          for (int w = 0; w < NW; w++) {
