@@ -20,7 +20,7 @@ struct gpumap_batch {
    std::vector<int64_t> offsets;     // host copy (n_reads + 1)
    DevBuf reads, reads4, read_len, len_row, row_len, phases, phase_rec, phase_lo, status;
    DevBuf up_src, up_off;            // staging of the upload (kept by a batch that is refilled)
-   DevBuf hits, hit_sizes, hit_off, direct, longer, keys, keys_alt, read_cnt, read_first;
+   DevBuf hits, hit_sizes, hit_off, direct, vsteps, longer, keys, keys_alt, read_cnt, read_first;
    DevBuf loc_read, loc_pos, loc_fwd, loc_seq, loc_seqpos, loc_strand, loc_score;
    DevBuf hkeys, hkeys_alt, hidx, hidx_alt, hit_read, hit_fp, hit_rp, hit_sz, hit_dp, hit_score, hit_align;
    bool length_seen[MAX_READ + 1];
@@ -32,7 +32,7 @@ struct gpumap_batch {
    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};      // [4]: between k_search and k_verify
    void release()
    {
-      for (DevBuf *b : {&up_src, &up_off, &reads, &reads4, &read_len, &len_row, &row_len, &phases, &phase_rec, &phase_lo, &status, &hits, &hit_sizes, &hit_off, &direct, &longer, &keys, &keys_alt,
+      for (DevBuf *b : {&up_src, &up_off, &reads, &reads4, &read_len, &len_row, &row_len, &phases, &phase_rec, &phase_lo, &status, &hits, &hit_sizes, &hit_off, &direct, &vsteps, &longer, &keys, &keys_alt,
                         &read_cnt, &read_first, &loc_read, &loc_pos, &loc_fwd, &loc_seq, &loc_seqpos, &loc_strand,
                         &loc_score, &hkeys, &hkeys_alt, &hidx, &hidx_alt, &hit_read, &hit_fp, &hit_rp, &hit_sz,
                         &hit_dp, &hit_score, &hit_align})
@@ -645,12 +645,14 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
          V.reads4 = b->reads4.as<const uint8_t>();
          V.reads = b->reads.as<const uint8_t>(); V.row_len = b->row_len.as<const uint16_t>();
          V.phase_rec = b->phase_rec.as<const uint2>(); V.phase_lo = b->phase_lo.as<const uint8_t>();
-         V.list = b->hits.as<const Node>(); V.n_list = H; V.stride = b->stride; V.n_ext = cnt + 8;
+         V.list = b->hits.as<const Node>(); V.n_list = H; V.stride = b->stride;
          V.direct = b->direct.as<unsigned long long>(); V.sizes = b->hit_sizes.as<int64_t>();
          V.key_shift = pos_bits + 4;
          const int vbd = 256;
          const bool pairs = use_verify == 2;                             // two lanes per entry
          const dim3 vgrid((unsigned)cdiv((pairs ? 2 : 1) * V.n_list, vbd));
+         HIP_TRY(b->vsteps.ensure(8 * (size_t)vgrid.x));
+         V.n_ext = b->vsteps.as<unsigned long long>();
 #define GM_VERIFY(N) do { if (pairs) hipLaunchKernelGGL((k_verify<N, true>), vgrid, dim3(vbd), 0, st, V); \
                           else hipLaunchKernelGGL((k_verify<N, false>), vgrid, dim3(vbd), 0, st, V); } while (0)
          switch (cdiv(b->maxlen, 64)) {                                 // 64-letter pieces of the longest read
@@ -660,6 +662,7 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
             default: GM_VERIFY(4); break;
          }
 #undef GM_VERIFY
+         hipLaunchKernelGGL(k_sum_steps, dim3(64), dim3(256), 0, st, b->vsteps.as<const unsigned long long>(), (int64_t)vgrid.x, cnt + 8);
          HIP_TRY(hipGetLastError());
          HIP_TRY(hipMemcpyAsync(host_cnt, cnt, sizeof host_cnt, hipMemcpyDeviceToHost, st));
          HIP_TRY(hipStreamSynchronize(st));

@@ -290,7 +290,7 @@ struct VerifyArgs {
    const Node *list;
    int64_t n_list;
    int stride;
-   unsigned long long *n_ext;      // [64] partial sums (one hot address would serialise the waves)
+   unsigned long long *n_ext;      // [blocks of the launch] steps per block (atomics on a few hot words cost a fifth of the kernel)
    unsigned long long *direct;     // [n_list][2] sort keys of the hits a candidate (one or two suffixes) became, ~0 = none
    int64_t *sizes;                 // [n_list] slots of the entry in the located output: such hits, or the suffixes of an interval
    int key_shift;                  // key = read << key_shift | text position << 4 | score (as k_place)
@@ -550,7 +550,22 @@ __global__ void __launch_bounds__(256) k_verify(VerifyArgs A)
    }
    steps -= shared;
    for (int o = 32; o > 0; o >>= 1) steps += (uint32_t)__shfl_xor((int)steps, o);
-   if ((threadIdx.x & 63) == 0 && steps) atomicAdd(A.n_ext + (blockIdx.x & 63), (unsigned long long)steps);
+   __shared__ uint32_t s_steps[4];
+   if ((threadIdx.x & 63) == 0) s_steps[threadIdx.x >> 6] = steps;
+   __syncthreads();
+   if (threadIdx.x == 0) A.n_ext[blockIdx.x] = (unsigned long long)s_steps[0] + s_steps[1] + s_steps[2] + s_steps[3];
+}
+
+// The steps of a k_verify launch: 64 blocks add up the per-block counts, one sum per block (what the host adds up).
+__global__ void __launch_bounds__(256) k_sum_steps(const unsigned long long *part, int64_t n, unsigned long long *out)
+{
+   unsigned long long v = 0;
+   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) v += part[i];
+   for (int o = 32; o > 0; o >>= 1) v += (unsigned long long)__shfl_xor((long long)v, o);
+   __shared__ unsigned long long s_sum[4];
+   if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = v;
+   __syncthreads();
+   if (threadIdx.x == 0) out[blockIdx.x] = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
 }
 
 // Selection by a per-lane index, written over values (not over the array) so that the arrays stay
