@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--waves-per-cu", type=int, default=0)
+    ap.add_argument("--verify", type=int, default=-1, help="option 'verify' of the library (-1 = its default by text size)")
     ap.add_argument("--device-build", action="store_true", help="generate and index in HBM also for the small workloads")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N > 1 "
                     "on a box with fewer GPUs than ranks: ranks then share devices)")
@@ -167,6 +168,8 @@ def main():
         t_bcast = time.time() - t0
     if args.waves_per_cu:
         ctx.set_option("waves_per_cu", args.waves_per_cu)
+    if args.verify >= 0:
+        ctx.set_option("verify", args.verify)
 
     # this rank's shard: its own reads (weak scaling), resident in HBM before the timed region
     if on_device:
