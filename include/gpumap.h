@@ -139,6 +139,15 @@ int gpumap_occ_all(gpumap_ctx *ctx, int64_t n, const int64_t *ptr, int64_t *occ)
 ** extension by symbol j at `end` (GPUMAP_QUERY_PREFIX / _SUFFIX); depth is the caller's dp + 1. */
 int gpumap_query_all(gpumap_ctx *ctx, int end, int64_t n, const int64_t *fp, const int64_t *rp,
                      const int64_t *sz, int64_t *out);
+/* gpumap_query_all without any allocation.  No counterpart in the reference: it is for callers that cannot
+** call hipMalloc (code under HIP graph capture, tight serving loops, harnesses that forbid allocation).
+** Same arguments and results as gpumap_query_all, at most GPUMAP_NOALLOC_MAX_QUERIES intervals per call
+** (-1 with a message beyond that).  The staging buffers are a static device array of 2.25 MiB that every GPU the
+** library runs on holds until the process ends; every call on a GPU shares it, so calls that overlap
+** on one GPU (also through different contexts) race: serialise them. */
+#define GPUMAP_NOALLOC_MAX_QUERIES 16384
+int gpumap_query_all_noalloc(gpumap_ctx *ctx, int end, int64_t n, const int64_t *fp, const int64_t *rp,
+                             const int64_t *sz, int64_t *out);
 /* sar_get (src/index_sar.c:92-118) for n positions; out-of-range positions give -1. */
 int gpumap_sar_get(gpumap_ctx *ctx, int64_t n, const int64_t *pos, int64_t *out);
 /* sar_get_range (src/index_sar.c:121-161). */

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libgpumap.so")
 QUERY_PREFIX, QUERY_SUFFIX = 0, 1
 MAX_TAU = 7
 MAX_READ_LEN = 256
+NOALLOC_MAX_QUERIES = 16384
 
 
 def build_library(force=False):
@@ -72,6 +73,7 @@ API = {
     "gpumap_create_from_device": (_P, [C.POINTER(DevIndex), _P, _I]),
     "gpumap_occ_all": (_I, [_P, _I64, _P, _P]),
     "gpumap_query_all": (_I, [_P, _I, _I64, _P, _P, _P, _P]),
+    "gpumap_query_all_noalloc": (_I, [_P, _I, _I64, _P, _P, _P, _P]),
     "gpumap_sar_get": (_I, [_P, _I64, _P, _P]),
     "gpumap_sar_get_range": (_I, [_P, _I64, _I64, _P]),
     "gpumap_encode": (_I, [_P, _P, _P, _I64, _P]),
@@ -328,6 +330,14 @@ class Context:
         out = np.empty((len(fp), 5, 3), dtype=np.int64)
         if lib().gpumap_query_all(self._h, end, len(fp), _ptr(fp), _ptr(rp), _ptr(sz), _ptr(out)) != 0:
             raise GpumapError("gpumap_query_all failed")
+        return out
+
+    def query_all_noalloc(self, end, fp, rp, sz):
+        """gpumap_query_all_noalloc: at most NOALLOC_MAX_QUERIES intervals, staged in the library's static scratch."""
+        fp, rp, sz = (np.ascontiguousarray(x, dtype=np.int64) for x in (fp, rp, sz))
+        out = np.empty((len(fp), 5, 3), dtype=np.int64)
+        if lib().gpumap_query_all_noalloc(self._h, end, len(fp), _ptr(fp), _ptr(rp), _ptr(sz), _ptr(out)) != 0:
+            raise GpumapError("gpumap_query_all_noalloc failed (see stderr)")
         return out
 
     def sar_get(self, pos):

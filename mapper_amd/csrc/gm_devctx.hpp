@@ -82,6 +82,8 @@ struct gpumap_ctx {
    int cu_count = 256;
    int waves_per_cu = 0;              // 0 = default (12)
    int64_t spill_cap = 16384;         // nodes per wave
+   // device address, on this context's GPU, of the static scratch array of gpumap_query_all_noalloc (gm_device.hip)
+   void *noalloc_scratch = nullptr;
    // scratch kept across runs
    DevBuf spill, counters, op_in, op_out, cub_tmp;
    // option "pinned_results": results are fetched into one page-locked arena owned by the context

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "gm_devctx.hpp"
@@ -45,10 +46,42 @@ struct gpumap_batch {
 // Context
 // ------------------------------------------------------------------------------------------------
 
+// ------------------------------------------------------------------------------------------------
+// Scratch of the allocation-free entry point (gpumap_query_all_noalloc): staging of the intervals and of
+// their extensions.  The array lives in the code object, every GPU holds its own copy at its own
+// address; `scratch` below is only the host-side stand-in of the symbol, the device address is looked
+// up once per device (gm_scratch_address) and only that pointer goes to copies and kernels.
+// ------------------------------------------------------------------------------------------------
+constexpr size_t NOALLOC_IN_BYTES = 24 * (size_t)GPUMAP_NOALLOC_MAX_QUERIES;       // fp, rp, sz
+constexpr size_t NOALLOC_OUT_BYTES = 120 * (size_t)GPUMAP_NOALLOC_MAX_QUERIES;     // 5 x {fp, rp, sz}
+static __device__ __align__(256) unsigned char scratch[NOALLOC_IN_BYTES + NOALLOC_OUT_BYTES];   // 2.25 MiB per GPU
+constexpr int SCRATCH_MAX_DEVICES = 64;
+static void *g_scratch_ptr[SCRATCH_MAX_DEVICES];
+static std::mutex g_scratch_mutex;
+
+// Device address of `scratch` on `device`, which must be the current device.  nullptr on failure.
+static void *gm_scratch_address(int device)
+{
+   if (device < 0 || device >= SCRATCH_MAX_DEVICES) return nullptr;
+   std::lock_guard<std::mutex> lock(g_scratch_mutex);
+   if (g_scratch_ptr[device] == nullptr) {
+      void *p = nullptr;
+      const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+      if (e != hipSuccess) {
+         std::fprintf(stderr, "%s\t(%s:%d) error: hipGetSymbolAddress: %s\n", __func__, __FILE__, __LINE__, hipGetErrorString(e));
+         return nullptr;
+      }
+      g_scratch_ptr[device] = p;
+   }
+   return g_scratch_ptr[device];
+}
+
 int gm_ctx_common_init(gpumap_ctx *ctx, int device)
 {
    hipDeviceProp_t prop;
    HIP_TRY(hipSetDevice(device));
+   ctx->noalloc_scratch = gm_scratch_address(device);
+   GM_FAIL_IF(ctx->noalloc_scratch == nullptr, "cannot resolve the device address of the static scratch array.");
    HIP_TRY(hipGetDeviceProperties(&prop, device));
    ctx->device = device;
    ctx->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -352,6 +385,37 @@ extern "C" int gpumap_query_all(gpumap_ctx *ctx, int end, int64_t n, const int64
    HIP_TRY(hipGetLastError());
    HIP_TRY(hipMemcpyAsync(out, ctx->op_out.p, 120 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
    HIP_TRY(hipStreamSynchronize(ctx->stream));
+   return 0;
+failure_return:
+   return -1;
+}
+
+// gpumap_query_all for callers that cannot allocate: the staging of gpumap_query_all (op_in / op_out, grown with
+// hipMalloc) is the static `scratch` array, through the device address looked up at context creation.  No
+// hipMalloc / hipFree here.  Nothing in the scratch has to start at zero: k_query_all writes all 15 words of
+// every one of the n outputs that are copied back.  Calls that overlap on one GPU share the array and race.
+extern "C" int gpumap_query_all_noalloc(gpumap_ctx *ctx, int end, int64_t n, const int64_t *fp, const int64_t *rp,
+                                        const int64_t *sz, int64_t *out)
+{
+   GM_FAIL_IF(ctx == nullptr, "argument 'ctx' is NULL.");
+   GM_FAIL_IF(end != GPUMAP_QUERY_SUFFIX && end != GPUMAP_QUERY_PREFIX, "invalid 'end' flag.");
+   GM_FAIL_IF(n < 0 || (n > 0 && (!fp || !rp || !sz || !out)), "invalid arguments.");
+   GM_FAIL_IF(n > GPUMAP_NOALLOC_MAX_QUERIES, "more than GPUMAP_NOALLOC_MAX_QUERIES intervals in one allocation-free call.");
+   GM_FAIL_IF(ctx->noalloc_scratch == nullptr, "the context has no static scratch.");
+   if (n == 0) return 0;
+   HIP_TRY(hipSetDevice(ctx->device));
+   {
+      int64_t *d = reinterpret_cast<int64_t *>(ctx->noalloc_scratch);
+      int64_t *d_out = reinterpret_cast<int64_t *>(static_cast<unsigned char *>(ctx->noalloc_scratch) + NOALLOC_IN_BYTES);
+      HIP_TRY(hipMemcpyAsync(d, fp, 8 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+      HIP_TRY(hipMemcpyAsync(d + n, rp, 8 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+      HIP_TRY(hipMemcpyAsync(d + 2 * n, sz, 8 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+      hipLaunchKernelGGL(k_query_all, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, ctx->stream, ctx->ix, end, n,
+                         (const int64_t *)d, (const int64_t *)(d + n), (const int64_t *)(d + 2 * n), d_out);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipMemcpyAsync(out, d_out, 120 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+   }
    return 0;
 failure_return:
    return -1;
