@@ -58,7 +58,7 @@ typedef struct {
    int64_t         sar_bits;
    int64_t         sar_len;        /* in 64-bit words */
    /* .txt */
-   int64_t         txt_len;        /* n = 2 * (sum of sequence lengths incl. separators) */
+   int64_t         txt_len;        /* n = 2 * (sum of sequence lengths incl. separators); 2 <= n < 2^33 */
    int64_t         seq_cnt;
    const int64_t  *seq_len;        /* [seq_cnt] */
    const int64_t  *seq_beg;        /* [seq_cnt] */
@@ -186,7 +186,8 @@ typedef struct {
    uint8_t  *loc_score;       /* [n_locs] mismatches (query N not counted, as in the reference)  */
 
    /* Interval hits = content of tree->stack after blocksearch_trail_rec (spath_t,
-   ** src/blocksearch.h:16-20), sorted by (read, fp).  Filled when want_intervals != 0. */
+   ** src/blocksearch.h:16-20), sorted by (read, fp) (the reference's order is the order of its depth-first
+   ** search; the sets are equal).  Filled when want_intervals != 0; at most 2^24 reads per batch then. */
    int64_t   n_hits;
    int64_t  *hit_read, *hit_fp, *hit_rp, *hit_sz, *hit_dp, *hit_score;   /* [n_hits] */
    uint64_t *hit_align;       /* [n_hits][GPUMAP_ALIGN_WORDS] mismatch + query-N bitmap */
@@ -195,12 +196,22 @@ typedef struct {
    ** calls of the reference schedule) and device milliseconds of the stages. */
    int64_t   n_ext;
    float     ms_search, ms_locate, ms_sort, ms_total;
-   /* Not NULL: the arrays lie in the context's pinned result arena (option "pinned_results": two
-   ** arenas used in turn) and stay valid until the second gpumap_batch_fetch / gpumap_map_batch after
-   ** this one on that context, so that one result can be consumed while the next is fetched;
-   ** gpumap_hits_free then only clears the struct. */
+   /* Not NULL: the arrays lie in a page-locked result arena of the batch (option "pinned_results": two
+   ** arenas used in turn) and stay valid until the second gpumap_batch_fetch after this one on that batch
+   ** (gpumap_map_batch: on that context), so that one result can be consumed while the next is fetched, and
+   ** no longer than the batch (the context); gpumap_hits_free then only clears the struct. */
    void     *arena;
+   /* Compact results (option "compact_results", or GPUMAP_PIPE_COMPACT): the located hits as their sorted 64-bit
+   ** keys, key = read << (key_pos_bits + 4) | text position << 4 | score; loc_read .. loc_score are then NULL
+   ** (8 bytes cross the link per hit instead of 42; everything else follows from the key: GPUMAP_KEY_*,
+   ** gpumap_hits_expand).  NULL in a full result. */
+   uint64_t *loc_key;         /* [n_locs] */
+   int32_t   key_pos_bits;    /* = sar_bits of the index */
+   int32_t   expanded;        /* gpumap_hits_expand has filled loc_read .. loc_score (malloc'ed) */
 } gpumap_hits;
+#define GPUMAP_KEY_SCORE(k)       ((int)((k) & 15))
+#define GPUMAP_KEY_POS(k, bits)   ((int64_t)(((k) >> 4) & ((1ull << (bits)) - 1ull)))
+#define GPUMAP_KEY_READ(k, bits)  ((int64_t)((k) >> ((bits) + 4)))
 
 /* Host buffers in, host arrays out (malloc'ed by the library, released by gpumap_hits_free).
 ** codes: concatenated symbol codes 0..4 (sym_str_index), offsets[n_reads+1]. */
@@ -224,6 +235,21 @@ int           gpumap_batch_refill_text(gpumap_ctx *ctx, gpumap_batch *batch, con
                                        const int64_t *offsets, int64_t n_reads);
 int           gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *batch, int tau, int want_intervals);
 int           gpumap_batch_fetch(gpumap_ctx *ctx, gpumap_batch *batch, gpumap_hits *out);
+/* An empty batch object (its own stream, scratch and result arenas: batches of one context can be filled, run
+** and fetched side by side from different threads), to be filled with gpumap_batch_stage / _refill_text. */
+gpumap_batch *gpumap_batch_new(gpumap_ctx *ctx);
+/* Stages the next chunk without encoding it: gpumap_batch_run then starts with the encoding (letters -> codes ->
+** bit planes on the device), so that the run covers encode + search + locate + order.  flags: GPUMAP_SRC_TEXT =
+** `src` holds letters (else codes 0..4); GPUMAP_SRC_DEVICE = `src` and `offsets` are device pointers that the
+** batch uses in place (no copy; they must stay valid until the run is over), else host pointers that are
+** copied to the device by the time the batch has been run. */
+#define GPUMAP_SRC_TEXT   1
+#define GPUMAP_SRC_DEVICE 2
+int           gpumap_batch_stage(gpumap_ctx *ctx, gpumap_batch *batch, const void *src, const int64_t *offsets,
+                                 int64_t n_reads, int flags);
+/* The arrays loc_read .. loc_score of a compact result, derived on the host from loc_key by the rule of
+** txt_pos_to_str / seq_bisect (src/index_txt.c:492-505, :770-787); malloc'ed, released by gpumap_hits_free. */
+int           gpumap_hits_expand(const gpumap_ctx *ctx, gpumap_hits *hits);
 /* Counters of the last run without copying hits: n_hits, n_locs, n_ext, and stage times (ms). */
 int           gpumap_batch_counters(const gpumap_batch *batch, int64_t *n_hits, int64_t *n_locs,
                                     int64_t *n_ext, float ms[4]);
@@ -236,7 +262,40 @@ int           gpumap_batch_counters(const gpumap_batch *batch, int64_t *n_hits, 
 ** of the wavefronts' reservations, stats[6], stats[7] = microseconds of k_search and of k_verify
 ** (HIP events on the library's stream; their sum is ms_search). */
 int           gpumap_batch_stats(const gpumap_batch *batch, int64_t stats[8]);
+/* More of the same: stats[0] = searches the run took (2: the first guess of the hit list's length was too short and
+** the search ran again with the exact length), stats[1] = microseconds of the encoding stage of a staged batch,
+** stats[2] = 1 when the run left compact results, stats[3] = capacity of the hit list in entries, stats[4] = chunks
+** of 64 nodes that the wavefronts' deques spilled to global memory; the rest is 0. */
+int           gpumap_batch_stats_ext(const gpumap_batch *batch, int64_t stats[8]);
 void          gpumap_batch_free(gpumap_batch *batch);
+
+/* ------------------------------------------------------------------------------------------
+** The loop of mapper() (src/mapper.c:23-40: read a chunk, work on it, print it, next chunk) as a pipeline:
+** `depth` batch objects, each with a worker thread and a stream of its own, so that the copy of chunk i+1 to
+** the device, the search of chunk i and the copy of the results of chunk i-1 to the host overlap.  Chunks
+** come back in the order they went in.  With several contexts (replicas of the index on several GPUs,
+** gpumap_multi) the chunks go round the GPUs: reads stay in input order.
+**   flags: GPUMAP_SRC_TEXT, GPUMAP_SRC_DEVICE (as gpumap_batch_stage), GPUMAP_PIPE_COMPACT (compact results).
+** Results lie in page-locked arenas of the pipe and stay valid until gpumap_pipe_release.
+** ---------------------------------------------------------------------------------------- */
+typedef struct gpumap_pipe gpumap_pipe;
+#define GPUMAP_PIPE_COMPACT 4
+gpumap_pipe *gpumap_pipe_create(gpumap_ctx *const *ctxs, int n_ctx, int depth, int tau, int flags);
+/* Hands a chunk to the pipe; blocks while all `depth` slots are taken (a slot is taken from submit to
+** release).  src / offsets must stay valid until the chunk's result has been returned.  `user` comes back
+** with the result. */
+int          gpumap_pipe_submit(gpumap_pipe *pipe, const void *src, const int64_t *offsets, int64_t n_reads, void *user);
+/* No more chunks will be submitted: gpumap_pipe_next returns 0 once everything has been returned. */
+void         gpumap_pipe_close(gpumap_pipe *pipe);
+/* Chunks submitted whose results have not been returned yet. */
+int64_t      gpumap_pipe_in_flight(gpumap_pipe *pipe);
+/* The next result in submit order: 1 = *out and *user filled, -1 = that chunk failed (its slot is released),
+** 0 = the pipe is closed and everything has been returned.  With nothing in flight and the pipe still open the call
+** waits for a submit from another thread: a single-threaded caller asks gpumap_pipe_in_flight first. */
+int          gpumap_pipe_next(gpumap_pipe *pipe, gpumap_hits *out, void **user);
+/* The caller is done with a result of gpumap_pipe_next: its slot takes the next chunk. */
+void         gpumap_pipe_release(gpumap_pipe *pipe, gpumap_hits *hits);
+void         gpumap_pipe_destroy(gpumap_pipe *pipe);
 
 /* ------------------------------------------------------------------------------------------
 ** mapper() (src/mapper.c:3-47, src/mapper.h:10): reads `qfile` (FASTQ / FASTA / raw, detected
@@ -246,11 +305,18 @@ void          gpumap_batch_free(gpumap_batch *batch);
 ** ---------------------------------------------------------------------------------------- */
 int gpumap_mapper(const char *qfile, const gpumap_index *index, gpumap_ctx *ctx, int tau,
                   const char *out_path);
+/* The same over replicas of the index on several GPUs (gpumap_multi_ctx): the chunks of the read file go round
+** the GPUs, the output is in input order, byte for byte what one GPU writes. */
+int gpumap_mapper_multi(const char *qfile, const gpumap_index *index, gpumap_ctx *const *ctxs, int n_ctx, int tau,
+                        const char *out_path);
 
 /* Options.  None changes a result, only where and how the work is done:
 **   "waves_per_cu"   persistent waves per CU of the search kernel (0 = as many as are resident)
 **   "spill_nodes"    per-wave spill capacity of the search deque, in nodes
-**   "pinned_results" 1 = gpumap_batch_fetch hands out slices of page-locked arenas of the context
+**   "pinned_results" 1 = gpumap_batch_fetch hands out slices of two page-locked arenas of the batch, used in turn
+**   "compact_results" 1 = located hits come back as sorted keys + CSR offsets (gpumap_hits.loc_key)
+**   "jump_bytes"     most bytes the jump table may take (0 = a third of the free device memory); rebuilds the table
+**   "hit_list_guess" first guess of the hit list's length in entries (0 = from the batch; a short guess costs a second search)
 **   "jump_k"         letters of the jump table (0 = none, -1 = by the size of the text and the free memory)
 **   "verify"         0 = every step on the Occ table; 1 = nodes of one suffix are finished on the text;
 **                    2 = also nodes of two suffixes; -1 = by the size of the text (the default) */

@@ -12,6 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libgpumap.so")
 QUERY_PREFIX, QUERY_SUFFIX = 0, 1
+SRC_TEXT, SRC_DEVICE, PIPE_COMPACT = 1, 2, 4
 MAX_TAU = 7
 MAX_READ_LEN = 256
 NOALLOC_MAX_QUERIES = 16384
@@ -54,6 +55,7 @@ class _Hits(C.Structure):
         ("hit_score", C.POINTER(C.c_int64)), ("hit_align", C.POINTER(C.c_uint64)),
         ("n_ext", C.c_int64), ("ms_search", C.c_float), ("ms_locate", C.c_float), ("ms_sort", C.c_float),
         ("ms_total", C.c_float), ("arena", C.c_void_p),
+        ("loc_key", C.POINTER(C.c_uint64)), ("key_pos_bits", C.c_int32), ("expanded", C.c_int32),
     ]
 
 
@@ -82,6 +84,18 @@ API = {
     "gpumap_batch_upload": (_P, [_P, _P, _P, _I64]),
     "gpumap_batch_upload_text": (_P, [_P, _P, _P, _I64]),
     "gpumap_batch_refill_text": (_I, [_P, _P, _P, _P, _I64]),
+    "gpumap_batch_new": (_P, [_P]),
+    "gpumap_batch_stage": (_I, [_P, _P, _P, _P, _I64, _I]),
+    "gpumap_hits_expand": (_I, [_P, C.POINTER(_Hits)]),
+    "gpumap_batch_stats_ext": (_I, [_P, C.POINTER(_I64)]),
+    "gpumap_pipe_create": (_P, [C.POINTER(_P), _I, _I, _I, _I]),
+    "gpumap_pipe_submit": (_I, [_P, _P, _P, _I64, _P]),
+    "gpumap_pipe_close": (None, [_P]),
+    "gpumap_pipe_in_flight": (_I64, [_P]),
+    "gpumap_pipe_next": (_I, [_P, C.POINTER(_Hits), C.POINTER(_P)]),
+    "gpumap_pipe_release": (None, [_P, C.POINTER(_Hits)]),
+    "gpumap_pipe_destroy": (None, [_P]),
+    "gpumap_mapper_multi": (_I, [C.c_char_p, _P, C.POINTER(_P), _I, _I, C.c_char_p]),
     "gpumap_batch_run": (_I, [_P, _P, _I, _I]),
     "gpumap_batch_fetch": (_I, [_P, _P, C.POINTER(_Hits)]),
     "gpumap_batch_counters": (_I, [_P, C.POINTER(_I64), C.POINTER(_I64), C.POINTER(_I64), C.POINTER(C.c_float)]),
@@ -194,10 +208,19 @@ class Hits:
         self.n_reads, self.n_locs, self.n_hits, self.n_ext = R, L, H, raw.n_ext
         self.status = arr(raw.status, R, np.int64)
         self.read_first_loc = arr(raw.read_first_loc, R + 1, np.int64)
-        for k in ("loc_read", "loc_pos", "loc_fwd", "loc_seq", "loc_seqpos"):
-            setattr(self, k, arr(getattr(raw, k), L, np.int64))
-        self.loc_strand = arr(raw.loc_strand, L, np.uint8)
-        self.loc_score = arr(raw.loc_score, L, np.uint8)
+        self.key_pos_bits = raw.key_pos_bits
+        self.loc_key = arr(raw.loc_key, L, np.uint64) if raw.loc_key else None
+        if raw.loc_read:
+            for k in ("loc_read", "loc_pos", "loc_fwd", "loc_seq", "loc_seqpos"):
+                setattr(self, k, arr(getattr(raw, k), L, np.int64))
+            self.loc_strand = arr(raw.loc_strand, L, np.uint8)
+            self.loc_score = arr(raw.loc_score, L, np.uint8)
+        else:
+            # compact result: read, text position and score follow from the key (GPUMAP_KEY_*)
+            b = np.uint64(raw.key_pos_bits)
+            self.loc_read = (self.loc_key >> (b + np.uint64(4))).astype(np.int64)
+            self.loc_pos = ((self.loc_key >> np.uint64(4)) & ((np.uint64(1) << b) - np.uint64(1))).astype(np.int64)
+            self.loc_score = (self.loc_key & np.uint64(15)).astype(np.uint8)
         if raw.hit_read:
             for k in ("hit_read", "hit_fp", "hit_rp", "hit_sz", "hit_dp", "hit_score"):
                 setattr(self, k, arr(getattr(raw, k), H, np.int64))
@@ -240,17 +263,102 @@ class Batch:
                     ms_sort=ms[2], ms_total=ms[3], loop_passes=st[0], continuations=st[1], jumped_steps=st[2], list_entries=st[3],
                     verify_steps=st[4], list_length=st[5], us_k_search=st[6], us_k_verify=st[7])
 
-    def fetch(self):
+    def fetch(self, expand=False):
         raw = _Hits()
         if lib().gpumap_batch_fetch(self.ctx._h, self._h, C.byref(raw)) != 0:
             raise GpumapError("gpumap_batch_fetch failed (see stderr)")
+        if expand and lib().gpumap_hits_expand(self.ctx._h, C.byref(raw)) != 0:
+            raise GpumapError("gpumap_hits_expand failed")
         h = Hits(raw)
         lib().gpumap_hits_free(C.byref(raw))
         return h
 
+    def stage(self, src, offsets, flags=0):
+        """gpumap_batch_stage: host numpy arrays, or (flags & SRC_DEVICE) integer device pointers."""
+        if flags & SRC_DEVICE:
+            sp, op, n = C.c_void_p(int(src)), C.c_void_p(int(offsets[0])), int(offsets[1])
+        else:
+            self._src = np.ascontiguousarray(src, dtype=np.uint8)
+            self._off = np.ascontiguousarray(offsets, dtype=np.int64)
+            sp, op, n = _ptr(self._src), _ptr(self._off), len(self._off) - 1
+        if lib().gpumap_batch_stage(self.ctx._h, self._h, sp, op, n, flags) != 0:
+            raise GpumapError("gpumap_batch_stage failed (see stderr)")
+        self.n_reads = n
+
+    def stats_ext(self):
+        st = (_I64 * 8)()
+        if lib().gpumap_batch_stats_ext(self._h, st) != 0:
+            raise GpumapError("gpumap_batch_stats_ext failed")
+        return dict(attempts=st[0], us_encode=st[1], compact=st[2], hit_list_capacity=st[3], spill_chunks=st[4])
+
     def close(self):
         if self._h:
             lib().gpumap_batch_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Pipe:
+    """gpumap_pipe: chunks in, results out in the same order, the stages of consecutive chunks overlapping."""
+
+    def __init__(self, ctxs, depth, tau, flags):
+        self._ctxs = list(ctxs)
+        arr = (_P * len(ctxs))(*[c._h for c in ctxs])
+        self._h = lib().gpumap_pipe_create(arr, len(ctxs), depth, tau, flags)
+        if not self._h:
+            raise GpumapError("gpumap_pipe_create failed (see stderr)")
+        self.flags = flags
+        self._keep = {}
+        self._seq = 0
+
+    def submit(self, src, offsets, n_reads=None):
+        """Host numpy arrays (kept alive until the result is back), or with SRC_DEVICE integer device pointers + n_reads."""
+        self._seq += 1
+        if self.flags & SRC_DEVICE:
+            sp, op, n = C.c_void_p(int(src)), C.c_void_p(int(offsets)), int(n_reads)
+        else:
+            src = np.ascontiguousarray(src, dtype=np.uint8)
+            offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+            self._keep[self._seq] = (src, offsets)
+            sp, op, n = _ptr(src), _ptr(offsets), len(offsets) - 1
+        if lib().gpumap_pipe_submit(self._h, sp, op, n, C.c_void_p(self._seq)) != 0:
+            raise GpumapError("gpumap_pipe_submit failed (see stderr)")
+        return self._seq
+
+    def next_raw(self):
+        """(raw gpumap_hits, tag) or None when nothing is in flight; release_raw() when done with it."""
+        if lib().gpumap_pipe_in_flight(self._h) == 0:
+            return None
+        raw = _Hits()
+        user = _P()
+        rc = lib().gpumap_pipe_next(self._h, C.byref(raw), C.byref(user))
+        if rc < 0:
+            raise GpumapError("a chunk failed in the pipeline (see stderr)")
+        if rc == 0:
+            return None
+        self._keep.pop(user.value, None)
+        return raw, user.value
+
+    def release_raw(self, raw):
+        lib().gpumap_pipe_release(self._h, C.byref(raw))
+
+    def next(self):
+        got = self.next_raw()
+        if got is None:
+            return None
+        h = Hits(got[0])
+        self.release_raw(got[0])
+        return h
+
+    def close(self):
+        if self._h:
+            lib().gpumap_pipe_close(self._h)
+            lib().gpumap_pipe_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -362,6 +470,12 @@ class Context:
         return out
 
     # ---- mapping
+    def new_batch(self):
+        return Batch(self, lib().gpumap_batch_new(self._h), 0)
+
+    def pipe(self, depth=3, tau=2, flags=0, others=()):
+        return Pipe([self] + list(others), depth, tau, flags)
+
     def upload(self, codes, offsets):
         codes = np.ascontiguousarray(codes, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.int64)

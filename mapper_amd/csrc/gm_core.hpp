@@ -11,7 +11,7 @@
 #pragma once
 #include <cstdint>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define GM_HD __host__ __device__ __forceinline__
 #else
 #define GM_HD inline
@@ -147,7 +147,7 @@ GM_HD void pack_block(const uint64_t *ref_occ, int64_t mark_intv, int64_t n_ref_
 //   w5 phase(6) | dash(1)<<6 | score(3)<<7 | sref(3)<<10 | fw(1)<<13 | end(8)<<14 | tau(3)<<22 | diff(3)<<25 |
 //      first(3)<<28: a node pushed back as a continuation resumes with the candidate symbols >= first
 //   w6,w7 mismatch positions, one byte each, in the order found (at most 7); byte 7 of the pair
-//         holds (read length - 1)
+//         holds the row of the read's length in the phase tables (one row per read length of the batch)
 // A finished node (hit) is stored in the same format (pos field unused).
 // ------------------------------------------------------------------------------------------------
 struct Node {
@@ -157,7 +157,7 @@ struct Node {
 struct NodeR {      // unpacked, in registers
    int64_t  fp, rp, sz;
    uint32_t read;
-   uint64_t mm;     // mismatch positions + (m-1) << 56
+   uint64_t mm;     // mismatch positions + phase-table row << 56
    int pos, end, phase, score, sref, tau, diff;
    int first = 0;   // first candidate symbol still to be followed (continuations of k_search)
    bool dash, fw;

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cerrno>
 #include <cstdio>
+#include <vector>
 #include "gm_host.hpp"
 #include "gm_core.hpp"
 
@@ -84,14 +85,17 @@ struct gpumap_ctx {
    int64_t spill_cap = 16384;         // nodes per wave
    // device address, on this context's GPU, of the static scratch array of gpumap_query_all_noalloc (gm_device.hip)
    void *noalloc_scratch = nullptr;
-   // scratch kept across runs
-   DevBuf spill, counters, op_in, op_out, cub_tmp;
-   // option "pinned_results": results are fetched into one page-locked arena owned by the context
-   bool pinned_results = false;
-   void *pin_arena[2] = {nullptr, nullptr};     // page-locked result arenas, used in turn
-   size_t pin_cap[2] = {0, 0};
-   int pin_turn = 0;
+   // staging of the batched operators (gpumap_occ_all ...), on the context's own stream
+   DevBuf op_in, op_out;
+   // options read by gpumap_batch_run / gpumap_batch_fetch (batches own their streams, scratch and result arenas)
+   bool pinned_results = false;       // "pinned_results": fetch into page-locked arenas of the batch
+   bool compact_results = false;      // "compact_results": sorted 8-byte keys + CSR offsets instead of the structure of arrays
+   int64_t hit_guess = 0;             // "hit_list_guess": first guess of the hit list's length in entries (0 = by the batch; tests)
+   int64_t jump_budget = 0;           // "jump_bytes": most bytes the jump table may take (0 = a third of the free memory)
+   std::vector<int64_t> seq_beg_host; // seq_beg[] (for gpumap_hits_expand)
+   gpumap_batch *map_batch_obj = nullptr;   // gpumap_map_batch with "pinned_results": the batch whose arenas hold the results
 };
+
 
 
 // Repack of a reference-layout Occ array that already lies in device memory (d_ref_occ, d_c) into

@@ -14,33 +14,62 @@
 
 using namespace gm;
 
+// One batch of reads and everything its run needs: a batch has its own stream, counters, spill region and
+// sort scratch, so that batches of one context can be filled, run and fetched side by side from different
+// host threads (gm_pipe.cpp: the copy of one chunk's results overlaps the search of the next chunk).  The
+// context is only read while batches run.
 struct gpumap_batch {
    gpumap_ctx *ctx = nullptr;
+   hipStream_t stream = nullptr;
    int64_t n_reads = 0;
    int stride = 0, maxlen = 1;
-   std::vector<int64_t> offsets;     // host copy (n_reads + 1)
+   // the letters (or codes) of the reads in device memory: the library's copy of a host buffer (up_src, up_off;
+   // indexed relative to offsets[0]) or the caller's own device buffers
+   const uint8_t *d_src = nullptr;
+   const int64_t *d_off = nullptr;
+   bool src_relative = true, src_text = false, encoded = false;
+   DevBuf up_src, up_off, seen;
+   uint8_t *h_small = nullptr;       // page-locked: small read-backs (lengths seen, counters) and uploads (phase tables)
+   hipEvent_t ev_seen = nullptr;
    DevBuf reads, reads4, read_len, len_row, row_len, phases, phase_rec, phase_lo, status;
-   DevBuf up_src, up_off;            // staging of the upload (kept by a batch that is refilled)
    DevBuf hits, hit_sizes, hit_off, direct, vsteps, longer, keys, keys_alt, read_cnt, read_first;
    DevBuf loc_read, loc_pos, loc_fwd, loc_seq, loc_seqpos, loc_strand, loc_score;
    DevBuf hkeys, hkeys_alt, hidx, hidx_alt, hit_read, hit_fp, hit_rp, hit_sz, hit_dp, hit_score, hit_align;
+   DevBuf spill, counters, cub_tmp;
+   const unsigned long long *sorted_keys = nullptr;     // the located hits' keys after the sort (in keys or keys_alt)
+   int key_pos_bits = 0;
+   bool compact = false;             // the last run left keys + CSR offsets only (no structure of arrays)
    bool length_seen[MAX_READ + 1];
    int64_t n_hits = 0, n_real = 0, n_locs = 0, n_ext = 0;
    int64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+   int64_t spill_chunks = 0;         // chunks of SPILL_CHUNK nodes the deques of the last search moved to global memory
+   int attempts = 0;                 // searches the last run took (2: the first guess of the hit list was too short)
    bool have_intervals = false, ran = false;
    int tau = 0;
    float ms[4] = {0, 0, 0, 0};
-   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};      // [4]: between k_search and k_verify
+   float ms_encode = 0;
+   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      // [4]: between k_search and k_verify, [5]: before the encoding
+   // option "pinned_results": results are fetched into page-locked arenas owned by the batch, used in turn
+   void *pin_arena[2] = {nullptr, nullptr};
+   size_t pin_cap[2] = {0, 0};
+   int pin_turn = 0;
    void release()
    {
-      for (DevBuf *b : {&up_src, &up_off, &reads, &reads4, &read_len, &len_row, &row_len, &phases, &phase_rec, &phase_lo, &status, &hits, &hit_sizes, &hit_off, &direct, &vsteps, &longer, &keys, &keys_alt,
+      for (DevBuf *b : {&up_src, &up_off, &seen, &reads, &reads4, &read_len, &len_row, &row_len, &phases, &phase_rec, &phase_lo, &status, &hits, &hit_sizes, &hit_off, &direct, &vsteps, &longer, &keys, &keys_alt,
                         &read_cnt, &read_first, &loc_read, &loc_pos, &loc_fwd, &loc_seq, &loc_seqpos, &loc_strand,
                         &loc_score, &hkeys, &hkeys_alt, &hidx, &hidx_alt, &hit_read, &hit_fp, &hit_rp, &hit_sz,
-                        &hit_dp, &hit_score, &hit_align})
+                        &hit_dp, &hit_score, &hit_align, &spill, &counters, &cub_tmp})
          b->release();
       for (auto &e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+      if (ev_seen) { (void)hipEventDestroy(ev_seen); ev_seen = nullptr; }
+      for (void *&a : pin_arena) if (a) { (void)hipHostFree(a); a = nullptr; }
+      pin_cap[0] = pin_cap[1] = 0;
+      if (h_small) { (void)hipHostFree(h_small); h_small = nullptr; }
+      if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
    }
 };
+constexpr int CNT_WORDS = 16;       // [0] cursor [1] hits [2] n_ext [3] error [4..8] stats of k_search (SearchArgs::stats)
+constexpr size_t H_SMALL_BYTES = 1 << 17;      // lengths seen | phase tables of up to 256 read lengths | counters
 
 // ------------------------------------------------------------------------------------------------
 // Context
@@ -88,7 +117,6 @@ int gm_ctx_common_init(gpumap_ctx *ctx, int device)
    HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
    HIP_TRY(hipMalloc((void **)&ctx->d_sym_table, 256));
    HIP_TRY(hipMemcpy(ctx->d_sym_table, ctx->sym_table, 256, hipMemcpyHostToDevice));
-   HIP_TRY(ctx->counters.ensure(8 * (8 + 64 + 1)));      // 8 counters + 64 partial sums of k_verify + the count of long intervals (k_place)
    return 0;
 failure_return:
    return -1;
@@ -99,6 +127,7 @@ extern "C" void gpumap_destroy(gpumap_ctx *ctx)
    if (!ctx) return;
    (void)hipSetDevice(ctx->device);
    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+   if (ctx->map_batch_obj) { gpumap_batch_free(ctx->map_batch_obj); ctx->map_batch_obj = nullptr; }
    if (ctx->owns_index) {
       if (ctx->d_occ) (void)hipFree(ctx->d_occ);
       if (ctx->d_tables) (void)hipFree(ctx->d_tables);
@@ -109,8 +138,7 @@ extern "C" void gpumap_destroy(gpumap_ctx *ctx)
    if (ctx->d_ref_occ) (void)hipFree(ctx->d_ref_occ);
    if (ctx->d_text && ctx->owns_text) (void)hipFree(ctx->d_text);
    if (ctx->d_sym_table) (void)hipFree(ctx->d_sym_table);
-   for (DevBuf *b : {&ctx->spill, &ctx->counters, &ctx->op_in, &ctx->op_out, &ctx->cub_tmp}) b->release();
-   for (void *a : ctx->pin_arena) if (a) (void)hipHostFree(a);
+   for (DevBuf *b : {&ctx->op_in, &ctx->op_out}) b->release();
    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
    delete ctx;
 }
@@ -129,11 +157,14 @@ int gm_ctx_build_jump(gpumap_ctx *ctx, int k)
    }
    if (k < 0) {
       // as many letters as keep the table at no more than one entry per text position, at most 16 (69 GB),
-      // and the table within a third of the memory that is free
+      // and the table within a third of the memory that is free, or within the byte budget the host
+      // application gave (option "jump_bytes" / GPUMAP_JUMP_BYTES)
       size_t free_b = 0, total_b = 0;
       HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+      if (ctx->jump_budget == 0 && getenv("GPUMAP_JUMP_BYTES")) ctx->jump_budget = atoll(getenv("GPUMAP_JUMP_BYTES"));
+      const size_t budget = ctx->jump_budget > 0 ? std::min<size_t>((size_t)ctx->jump_budget, free_b) : free_b / 3;
       k = 0;
-      while (k < 16 && ((int64_t)1 << (2 * (k + 1))) <= ctx->ix.n && ((size_t)16 << (2 * (k + 1))) <= free_b / 3) k++;
+      while (k < 16 && ((int64_t)1 << (2 * (k + 1))) <= ctx->ix.n && ((size_t)16 << (2 * (k + 1))) <= budget) k++;
       if (k < 4) k = 0;
    }
    GM_FAIL_IF(k > 16, "jump_k out of range.");
@@ -163,6 +194,7 @@ int gm_ctx_repack(gpumap_ctx *ctx, const uint64_t *d_ref_occ, const uint64_t *d_
    ix.n_blocks = num_blocks(ix.n);
    ix.n_super = num_supers(ix.n);
    ix.seq_cnt = (int32_t)seq_cnt;
+   ctx->seq_beg_host.assign(seq_beg_host, seq_beg_host + seq_cnt);
    ctx->occ_bytes = ix.n_blocks * 64;
    ctx->tables_words = TAB_SBASE + SYMS * ix.n_super + seq_cnt;
    ctx->tables_bytes = ctx->tables_words * 8;
@@ -201,8 +233,11 @@ extern "C" gpumap_ctx *gpumap_create(const gpumap_index_view *v, int device)
    GM_FAIL_IF(v == nullptr, "argument 'view' is NULL.");
    GM_FAIL_IF(v->occ == nullptr || v->c == nullptr || v->sa == nullptr, "index view has NULL arrays.");
    GM_FAIL_IF(v->sym_count != SYMS, "only the 5-symbol DNA alphabet is supported.");
+   GM_FAIL_IF(v->sym_table == nullptr || v->com_table == nullptr, "index view has no symbol tables.");
    GM_FAIL_IF(v->occ_word_size != 64 || v->occ_mark_intv < 1, "unsupported Occ layout.");
-   GM_FAIL_IF(v->txt_len < 2 || v->txt_len >= ((int64_t)1 << 40), "text length out of range.");
+   // 2^33: the superblock counts of up to 256 superblocks are staged in LDS, and the Occ blocks of such a text
+   // stay below 4 GiB, which k_search addresses with 32-bit offsets
+   GM_FAIL_IF(v->txt_len < 2 || v->txt_len >= ((int64_t)1 << 33), "text length out of range (2 <= txt_len < 2^33).");
    GM_FAIL_IF(v->sar_bits < 1 || v->sar_bits > 40, "sar_bits out of range.");
    GM_FAIL_IF(v->seq_cnt < 1 || v->seq_beg == nullptr, "index view has no sequences.");
    {
@@ -318,6 +353,8 @@ extern "C" gpumap_ctx *gpumap_create_from_device(const gpumap_devindex *dev, con
    ctx->ix.tables = (const uint64_t *)ctx->d_tables;
    ctx->ix.sa = (const uint64_t *)ctx->d_sa;
    ctx->ix.seq_beg = (const int64_t *)((const uint64_t *)ctx->d_tables + TAB_SBASE + SYMS * h.n_super);
+   ctx->seq_beg_host.resize((size_t)h.seq_cnt);
+   HIP_TRY(hipMemcpy(ctx->seq_beg_host.data(), ctx->ix.seq_beg, 8 * (size_t)h.seq_cnt, hipMemcpyDeviceToHost));
    GM_FAIL_IF(gm_ctx_build_jump(ctx, getenv("GPUMAP_JUMP_K") ? atoi(getenv("GPUMAP_JUMP_K")) : -1) != 0, "cannot build the jump table.");
    return ctx;
 failure_return:
@@ -330,9 +367,12 @@ extern "C" int gpumap_set_option(gpumap_ctx *ctx, const char *name, int64_t valu
    GM_FAIL_IF(ctx == nullptr || name == nullptr, "NULL argument.");
    if (!strcmp(name, "waves_per_cu")) { GM_FAIL_IF(value < 0 || value > 32, "waves_per_cu out of range."); ctx->waves_per_cu = (int)value; }
    else if (!strcmp(name, "pinned_results")) ctx->pinned_results = value != 0;
+   else if (!strcmp(name, "compact_results")) ctx->compact_results = value != 0;
+   else if (!strcmp(name, "hit_list_guess")) { GM_FAIL_IF(value < 0, "hit_list_guess out of range."); ctx->hit_guess = value; }
+   else if (!strcmp(name, "jump_bytes")) { GM_FAIL_IF(value < 0, "jump_bytes out of range."); ctx->jump_budget = value; HIP_TRY(hipSetDevice(ctx->device)); GM_FAIL_IF(gm_ctx_build_jump(ctx, -1) != 0, "cannot build the jump table."); }
    else if (!strcmp(name, "verify")) { GM_FAIL_IF(value < -1 || value > 2, "verify out of range."); ctx->verify = (int)value; }
    else if (!strcmp(name, "jump_k")) { HIP_TRY(hipSetDevice(ctx->device)); GM_FAIL_IF(gm_ctx_build_jump(ctx, (int)value) != 0, "cannot build the jump table."); }
-   else if (!strcmp(name, "spill_nodes")) { GM_FAIL_IF(value < 0 || value > (1 << 22), "spill_nodes out of range."); ctx->spill_cap = value ? ((value + SPILL_CHUNK - 1) / SPILL_CHUNK) * SPILL_CHUNK : 16384; }
+   else if (!strcmp(name, "spill_nodes")) { GM_FAIL_IF(value < 0 || value > (1 << 22), "spill_nodes out of range."); ctx->spill_cap = value ? ((value + SPILL_CHUNK - 1) / SPILL_CHUNK) * SPILL_CHUNK : 16384; }   // (batches size their spill regions at their next run)
    else GM_FAIL("unknown option.");
    return 0;
 failure_return:
@@ -487,55 +527,110 @@ extern "C" void gpumap_batch_free(gpumap_batch *b)
 {
    if (!b) return;
    if (b->ctx) (void)hipSetDevice(b->ctx->device);
+   if (b->stream) (void)hipStreamSynchronize(b->stream);
    b->release();
    delete b;
 }
 
+extern "C" gpumap_batch *gpumap_batch_new(gpumap_ctx *ctx)
+{
+   gpumap_batch *b = nullptr;
+   GM_FAIL_IF(ctx == nullptr, "argument 'ctx' is NULL.");
+   HIP_TRY(hipSetDevice(ctx->device));
+   b = new gpumap_batch();
+   b->ctx = ctx;
+   memset(b->length_seen, 0, sizeof b->length_seen);
+   HIP_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+   HIP_TRY(hipHostMalloc((void **)&b->h_small, H_SMALL_BYTES, hipHostMallocDefault));
+   HIP_TRY(hipEventCreateWithFlags(&b->ev_seen, hipEventDisableTiming));
+   for (auto &e : b->ev) HIP_TRY(hipEventCreate(&e));
+   HIP_TRY(b->seen.ensure(SEEN_BYTES));
+   HIP_TRY(b->counters.ensure(8 * (CNT_WORDS + 64 + 1)));      // counters + 64 partial sums of k_verify + the count of long intervals (k_place)
+   return b;
+failure_return:
+   gpumap_batch_free(b);
+   return nullptr;
+}
+
+// Encoding of a filled batch: the lengths seen (k_read_lengths, read back by gm_batch_fill) size the read
+// matrix; letters (or codes) -> codes in fixed-stride rows (k_encode) and the rows as bit planes (k_pack_planes).
+static int batch_encode(gpumap_ctx *ctx, gpumap_batch *b)
+{
+   hipStream_t st = b->stream;
+   const int64_t n_reads = b->n_reads;
+   if (n_reads > 0) {
+      HIP_TRY(hipEventSynchronize(b->ev_seen));
+      const uint8_t *seen = b->h_small;
+      GM_FAIL_IF(seen[SEEN_ERROR] != 0, "offsets must not decrease.");
+      int64_t maxlen = 1;
+      for (int m = 0; m <= MAX_READ; m++) {
+         b->length_seen[m] = seen[m] != 0;
+         if (seen[m] && m > maxlen) maxlen = m;
+      }
+      b->stride = (int)((maxlen + 127) & ~(int64_t)127);    // the rows as bit planes come in units of 128 symbols
+      b->maxlen = (int)maxlen;
+      HIP_TRY(b->reads.ensure((size_t)n_reads * b->stride));
+      HIP_TRY(b->reads4.ensure((size_t)n_reads * (size_t)(12 * (b->stride / 32))));
+      int64_t threads = n_reads * b->stride;
+      hipLaunchKernelGGL(k_encode, dim3((unsigned)std::min<int64_t>(cdiv(threads, 256), 1 << 22)), dim3(256), 0, st,
+                         b->d_src, b->d_off, b->src_relative ? 1 : 0, n_reads, b->stride,
+                         b->src_text ? (const uint8_t *)ctx->d_sym_table : (const uint8_t *)nullptr, b->reads.as<uint8_t>());
+      const int64_t groups = n_reads * (b->stride / 32);
+      hipLaunchKernelGGL(k_pack_planes, dim3((unsigned)std::min<int64_t>(cdiv(groups, 256), 1 << 20)), dim3(256), 0, st,
+                         b->reads.as<const uint8_t>(), n_reads * b->stride, (uint8_t)0xff, b->reads4.as<uint32_t>(), groups);
+      HIP_TRY(hipGetLastError());
+   } else {
+      memset(b->length_seen, 0, sizeof b->length_seen);
+      b->stride = 128; b->maxlen = 1;
+   }
+   b->encoded = true;
+   return 0;
+failure_return:
+   return -1;
+}
+
 // Fills `b` with a new set of reads; the device buffers `b` already holds are kept and grow only when
 // the new set needs more (a caller that maps chunk after chunk pays for the allocations once).
-static int batch_fill(gpumap_ctx *ctx, gpumap_batch *b, const uint8_t *src, const int64_t *offsets, int64_t n_reads, bool is_text)
+// src_flags: GM_SRC_TEXT = letters, else codes; GM_SRC_DEVICE = src and offsets are device pointers, used in
+// place (they must stay valid until the batch has been run).  encode_now = false leaves the batch staged:
+// gm_batch_run encodes it first, inside its timed region.
+int gm_batch_fill(gpumap_ctx *ctx, gpumap_batch *b, const void *src, const int64_t *offsets, int64_t n_reads, int src_flags, bool encode_now)
 {
    GM_FAIL_IF(n_reads < 0 || offsets == nullptr, "invalid arguments.");
    GM_FAIL_IF(n_reads >= ((int64_t)1 << 31), "too many reads in one batch.");
    HIP_TRY(hipSetDevice(ctx->device));
-   b->ctx = ctx;
-   b->n_reads = n_reads;
-   b->ran = false; b->have_intervals = false;
-   b->offsets.assign(offsets, offsets + n_reads + 1);
-   memset(b->length_seen, 0, sizeof b->length_seen);
    {
-      int64_t maxlen = 1;
-      for (int64_t r = 0; r < n_reads; r++) {
-         int64_t len = offsets[r + 1] - offsets[r];
-         GM_FAIL_IF(len < 0, "offsets must not decrease.");
-         if (len <= MAX_READ) { b->length_seen[len] = true; maxlen = std::max(maxlen, len); }
-      }
-      b->stride = (int)((maxlen + 127) & ~(int64_t)127);    // the rows as bit planes come in units of 128 symbols
-      b->maxlen = (int)maxlen;
-      int64_t total = offsets[n_reads] - offsets[0];
-      GM_FAIL_IF(total > 0 && src == nullptr, "argument 'codes' is NULL.");
-      HIP_TRY(b->reads.ensure((size_t)std::max<int64_t>(1, n_reads) * b->stride));
-      HIP_TRY(b->reads4.ensure((size_t)std::max<int64_t>(1, n_reads) * (size_t)(12 * (b->stride / 32))));
+      hipStream_t st = b->stream;
+      b->n_reads = n_reads;
+      b->ran = false; b->have_intervals = false; b->encoded = false;
+      b->src_text = (src_flags & GM_SRC_TEXT) != 0;
       HIP_TRY(b->read_len.ensure(2 * (size_t)std::max<int64_t>(1, n_reads)));
       HIP_TRY(b->status.ensure(8 * (size_t)std::max<int64_t>(1, n_reads)));
-      for (auto &e : b->ev) if (!e) HIP_TRY(hipEventCreate(&e));
-      if (n_reads > 0) {
-         HIP_TRY(b->up_src.ensure((size_t)std::max<int64_t>(1, total)));
+      int64_t total = 0;
+      if (src_flags & GM_SRC_DEVICE) {
+         GM_FAIL_IF(n_reads > 0 && src == nullptr, "argument 'src' is NULL.");
+         b->d_src = (const uint8_t *)src; b->d_off = offsets; b->src_relative = false;
+      } else {
+         total = offsets[n_reads] - offsets[0];
+         GM_FAIL_IF(total < 0, "offsets must not decrease.");
+         GM_FAIL_IF(total > 0 && src == nullptr, "argument 'codes' is NULL.");
          HIP_TRY(b->up_off.ensure(8 * (size_t)(n_reads + 1)));
-         if (total > 0) HIP_TRY(hipMemcpyAsync(b->up_src.p, src + offsets[0], (size_t)total, hipMemcpyHostToDevice, ctx->stream));
-         std::vector<int64_t> rel((size_t)n_reads + 1);
-         for (int64_t r = 0; r <= n_reads; r++) rel[r] = offsets[r] - offsets[0];
-         HIP_TRY(hipMemcpyAsync(b->up_off.p, rel.data(), 8 * (size_t)(n_reads + 1), hipMemcpyHostToDevice, ctx->stream));
-         int64_t threads = n_reads * b->stride;
-         hipLaunchKernelGGL(k_encode, dim3((unsigned)std::min<int64_t>(cdiv(threads, 256), 1 << 22)), dim3(256), 0, ctx->stream,
-                            b->up_src.as<const uint8_t>(), b->up_off.as<const int64_t>(), n_reads, b->stride,
-                            is_text ? (const uint8_t *)ctx->d_sym_table : (const uint8_t *)nullptr,
-                            b->reads.as<uint8_t>(), b->read_len.as<uint16_t>(), (uint8_t *)nullptr);
-         const int64_t groups = n_reads * (b->stride / 32);
-         hipLaunchKernelGGL(k_pack_planes, dim3((unsigned)std::min<int64_t>(cdiv(groups, 256), 1 << 20)), dim3(256), 0, ctx->stream,
-                            b->reads.as<const uint8_t>(), n_reads * b->stride, (uint8_t)0xff, b->reads4.as<uint32_t>(), groups);
+         HIP_TRY(b->up_src.ensure((size_t)std::max<int64_t>(1, total)));
+         HIP_TRY(hipMemcpyAsync(b->up_off.p, offsets, 8 * (size_t)(n_reads + 1), hipMemcpyHostToDevice, st));
+         b->d_src = b->up_src.as<const uint8_t>(); b->d_off = b->up_off.as<const int64_t>(); b->src_relative = true;
+      }
+      if (n_reads > 0) {
+         HIP_TRY(hipMemsetAsync(b->seen.p, 0, SEEN_BYTES, st));
+         hipLaunchKernelGGL(k_read_lengths, dim3((unsigned)std::min<int64_t>(cdiv(n_reads, 256), 4096)), dim3(256), 0, st,
+                            b->d_off, n_reads, b->read_len.as<uint16_t>(), b->seen.as<uint8_t>());
          HIP_TRY(hipGetLastError());
-         HIP_TRY(hipStreamSynchronize(ctx->stream));
+         HIP_TRY(hipMemcpyAsync(b->h_small, b->seen.p, SEEN_BYTES, hipMemcpyDeviceToHost, st));
+         HIP_TRY(hipEventRecord(b->ev_seen, st));
+      }
+      if (total > 0) HIP_TRY(hipMemcpyAsync(b->up_src.p, (const uint8_t *)src + offsets[0], (size_t)total, hipMemcpyHostToDevice, st));
+      if (encode_now) {
+         GM_FAIL_IF(batch_encode(ctx, b) != 0, "cannot encode the batch.");
+         HIP_TRY(hipStreamSynchronize(st));             // the caller's buffers are free again
       }
    }
    return 0;
@@ -545,11 +640,11 @@ failure_return:
 
 static gpumap_batch *batch_upload(gpumap_ctx *ctx, const uint8_t *src, const int64_t *offsets, int64_t n_reads, bool is_text)
 {
-   gpumap_batch *b = nullptr;
-   GM_FAIL_IF(ctx == nullptr, "argument 'ctx' is NULL.");
-   b = new gpumap_batch();
-   GM_FAIL_IF(batch_fill(ctx, b, src, offsets, n_reads, is_text) != 0, "cannot upload the batch.");
+   gpumap_batch *b = gpumap_batch_new(ctx);
+   GM_FAIL_IF(b == nullptr, "cannot create the batch.");
+   GM_FAIL_IF(gm_batch_fill(ctx, b, src, offsets, n_reads, is_text ? GM_SRC_TEXT : 0, true) != 0, "cannot upload the batch.");
    b->up_src.release(); b->up_off.release();             // a one-off batch does not keep its staging
+   b->d_src = nullptr; b->d_off = nullptr;
    return b;
 failure_return:
    gpumap_batch_free(b);
@@ -561,24 +656,59 @@ extern "C" int gpumap_batch_refill_text(gpumap_ctx *ctx, gpumap_batch *b, const 
    GM_FAIL_IF(ctx == nullptr, "argument 'ctx' is NULL.");
    GM_FAIL_IF(b == nullptr, "argument 'batch' is NULL.");
    GM_FAIL_IF(b->ctx != ctx, "the batch belongs to another context.");
-   return batch_fill(ctx, b, (const uint8_t *)text, offsets, n_reads, true);
+   return gm_batch_fill(ctx, b, text, offsets, n_reads, GM_SRC_TEXT, true);
+failure_return:
+   return -1;
+}
+
+extern "C" int gpumap_batch_stage(gpumap_ctx *ctx, gpumap_batch *b, const void *src, const int64_t *offsets, int64_t n_reads, int flags)
+{
+   GM_FAIL_IF(ctx == nullptr, "argument 'ctx' is NULL.");
+   GM_FAIL_IF(b == nullptr, "argument 'batch' is NULL.");
+   GM_FAIL_IF(b->ctx != ctx, "the batch belongs to another context.");
+   GM_FAIL_IF(flags & ~(GPUMAP_SRC_TEXT | GPUMAP_SRC_DEVICE), "unknown flag.");
+   return gm_batch_fill(ctx, b, src, offsets, n_reads, flags, false);
 failure_return:
    return -1;
 }
 
 extern "C" gpumap_batch *gpumap_batch_upload(gpumap_ctx *ctx, const uint8_t *codes, const int64_t *offsets, int64_t n_reads)
 {
+   GM_FAIL_IF(ctx == nullptr, "argument 'ctx' is NULL.");
    return batch_upload(ctx, codes, offsets, n_reads, false);
+failure_return:
+   return nullptr;
 }
 
 extern "C" gpumap_batch *gpumap_batch_upload_text(gpumap_ctx *ctx, const char *text, const int64_t *offsets, int64_t n_reads)
 {
+   GM_FAIL_IF(ctx == nullptr, "argument 'ctx' is NULL.");
    return batch_upload(ctx, (const uint8_t *)text, offsets, n_reads, true);
+failure_return:
+   return nullptr;
 }
 
 static int bits_for(uint64_t v) { int b = 0; while (b < 64 && (v >> b)) b++; return b; }
 
-extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals)
+// Small uploads of one run (phase tables) go through the batch's page-locked block: the copies are asynchronous
+// and the block is only rewritten by the next run of the same batch, after this run's last synchronisation.
+struct SmallStage {
+   uint8_t *base;
+   size_t cap;
+   size_t used = 0;
+   template <class T> const T *put(const std::vector<T> &v)
+   {
+      const size_t bytes = sizeof(T) * v.size();
+      used = (used + 15) & ~(size_t)15;
+      if (used + bytes > cap) return nullptr;
+      T *p = reinterpret_cast<T *>(base + used);
+      memcpy(p, v.data(), bytes);
+      used += bytes;
+      return p;
+   }
+};
+
+int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, int result_flags)
 {
    GM_FAIL_IF(ctx == nullptr || b == nullptr, "NULL argument.");
    GM_FAIL_IF(b->ctx != ctx, "batch belongs to another context.");
@@ -586,11 +716,16 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
    GM_FAIL_IF(tau > MAX_TAU, "argument 'tau' exceeds GPUMAP_MAX_TAU.");
    HIP_TRY(hipSetDevice(ctx->device));
    {
-      hipStream_t st = ctx->stream;
+      hipStream_t st = b->stream;
       const int64_t R = b->n_reads;
+      const bool compact = (result_flags & GM_RESULT_COMPACT) != 0 && !want_intervals;
       b->tau = tau; b->ran = false; b->n_hits = b->n_locs = b->n_ext = 0; b->have_intervals = false;
+      b->sorted_keys = nullptr; b->compact = compact;
+      // ---- K4 (a staged batch): letters -> codes -> bit planes, inside the timed region
+      HIP_TRY(hipEventRecord(b->ev[5], st));
+      if (!b->encoded) GM_FAIL_IF(batch_encode(ctx, b) != 0, "cannot encode the batch.");
       // ---- schedule: one phase-table row per read length present (src/blocksearch.c:138-170)
-      std::vector<uint8_t> len_row(MAX_READ + 1, 0xff);
+      std::vector<uint16_t> len_row(MAX_READ + 1, NO_ROW);
       std::vector<uint32_t> phases, phase_rec;
       std::vector<uint8_t> phase_lo;
       std::vector<uint16_t> row_len;
@@ -602,8 +737,7 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
          memset(tab, 0, sizeof tab);
          memset(lo_tab, 0, sizeof lo_tab);
          if (!build_phase_table(m, tau, tab, lo_tab)) continue;        // the reference returns -1 for this length
-         GM_FAIL_IF(rows >= 255, "too many distinct read lengths.");
-         len_row[m] = (uint8_t)rows++;
+         len_row[m] = (uint16_t)rows++;                                 // at most 256 rows: the node keeps its row in one byte
          row_len.push_back((uint16_t)m);
          phases.insert(phases.end(), tab, tab + MAX_PHASES);
          phase_lo.insert(phase_lo.end(), lo_tab, lo_tab + MAX_PHASES);
@@ -615,22 +749,29 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
       }
       if (phases.empty()) { phases.assign(MAX_PHASES, 0); phase_rec.assign(2 * MAX_PHASES, 0); phase_lo.assign(MAX_PHASES, 0); }
       if (row_len.empty()) row_len.push_back(0);
-      HIP_TRY(b->len_row.ensure(MAX_READ + 1));
-      HIP_TRY(b->phases.ensure(4 * phases.size()));
-      HIP_TRY(b->phase_rec.ensure(4 * phase_rec.size()));
-      HIP_TRY(hipMemcpyAsync(b->phase_rec.p, phase_rec.data(), 4 * phase_rec.size(), hipMemcpyHostToDevice, st));
-      HIP_TRY(b->phase_lo.ensure(phase_lo.size()));
-      HIP_TRY(hipMemcpyAsync(b->phase_lo.p, phase_lo.data(), phase_lo.size(), hipMemcpyHostToDevice, st));
-      HIP_TRY(hipMemcpyAsync(b->len_row.p, len_row.data(), MAX_READ + 1, hipMemcpyHostToDevice, st));
-      HIP_TRY(b->row_len.ensure(2 * row_len.size()));
-      HIP_TRY(hipMemcpyAsync(b->row_len.p, row_len.data(), 2 * row_len.size(), hipMemcpyHostToDevice, st));
-      HIP_TRY(hipMemcpyAsync(b->phases.p, phases.data(), 4 * phases.size(), hipMemcpyHostToDevice, st));
+      {
+         SmallStage ss{b->h_small + 512, H_SMALL_BYTES - 512 - 1024};                               // (the first bytes hold the lengths seen)
+         const uint16_t *h_len_row = ss.put(len_row);
+         const uint32_t *h_phases = ss.put(phases), *h_rec = ss.put(phase_rec);
+         const uint8_t *h_lo = ss.put(phase_lo);
+         const uint16_t *h_row_len = ss.put(row_len);
+         GM_FAIL_IF(!h_len_row || !h_phases || !h_rec || !h_lo || !h_row_len, "phase tables do not fit the staging block.");
+         HIP_TRY(b->len_row.ensure(2 * len_row.size()));
+         HIP_TRY(b->phases.ensure(4 * phases.size()));
+         HIP_TRY(b->phase_rec.ensure(4 * phase_rec.size()));
+         HIP_TRY(b->phase_lo.ensure(phase_lo.size()));
+         HIP_TRY(b->row_len.ensure(2 * row_len.size()));
+         HIP_TRY(hipMemcpyAsync(b->phase_rec.p, h_rec, 4 * phase_rec.size(), hipMemcpyHostToDevice, st));
+         HIP_TRY(hipMemcpyAsync(b->phase_lo.p, h_lo, phase_lo.size(), hipMemcpyHostToDevice, st));
+         HIP_TRY(hipMemcpyAsync(b->len_row.p, h_len_row, 2 * len_row.size(), hipMemcpyHostToDevice, st));
+         HIP_TRY(hipMemcpyAsync(b->row_len.p, h_row_len, 2 * row_len.size(), hipMemcpyHostToDevice, st));
+         HIP_TRY(hipMemcpyAsync(b->phases.p, h_phases, 4 * phases.size(), hipMemcpyHostToDevice, st));
+      }
       if (R > 0) {
          hipLaunchKernelGGL(k_status, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, st, b->read_len.as<const uint16_t>(),
-                            b->len_row.as<const uint8_t>(), R, b->status.as<int64_t>());
+                            b->len_row.as<const uint16_t>(), R, b->status.as<int64_t>());
          HIP_TRY(hipGetLastError());
       }
-      HIP_TRY(hipStreamSynchronize(st));          // the staging vectors above go out of scope
 
       // ---- K2 search (rerun once with an exact buffer if the hit list overflowed)
       // persistent waves: as many workgroups as are resident at once (the staged superblock table grows with
@@ -647,10 +788,11 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
       const int wpc = ctx->waves_per_cu ? ctx->waves_per_cu : WG_WAVES * std::max(1, std::min(want_wg, resident_wg));
       const int n_wg = std::max(1, ctx->cu_count * wpc / WG_WAVES);
       const int64_t n_waves = (int64_t)n_wg * WG_WAVES;
-      HIP_TRY(ctx->spill.ensure((size_t)n_waves * (size_t)ctx->spill_cap * sizeof(Node)));
-      unsigned long long *cnt = ctx->counters.as<unsigned long long>();   // [0] cursor [1] hits [2] n_ext [3] error
-      unsigned long long host_cnt[8 + 64];
-      memset(host_cnt, 0, sizeof host_cnt);
+      HIP_TRY(b->spill.ensure((size_t)n_waves * (size_t)ctx->spill_cap * sizeof(Node)));
+      unsigned long long *cnt = b->counters.as<unsigned long long>();   // [0] cursor [1] hits [2] n_ext [3] error
+      unsigned long long *host_cnt = reinterpret_cast<unsigned long long *>(b->h_small + H_SMALL_BYTES - 1024);   // 8 + 64 words, page-locked
+      constexpr size_t CNT_BYTES = 8 * (CNT_WORDS + 64);
+      memset(host_cnt, 0, CNT_BYTES);
       // interval output needs the final interval of every hit: no short cut through the text then
       // 0: every step on the Occ table; 1: nodes of one suffix are finished on the text; 2: also nodes of two.
       // -1 (default): 2 for texts of 2^31 symbols and more, else 1 (measured: pairs pay where most k-mers of
@@ -659,21 +801,24 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
       const int use_verify = (verify_mode && ctx->d_text != nullptr && ctx->d_text4 != nullptr && !want_intervals) ? verify_mode : 0;
       // first guess of the list's length (a batch that is run or refilled again keeps the longer list): with
       // k_verify every seed can leave a candidate, plus what repeats add (5.5 entries per read at GRCh38
-      // size, tau 2); too short costs a second run of the search
-      size_t hit_cap = std::max<size_t>((size_t)1 << 16, (size_t)R * (use_verify ? (size_t)tau + 4 : 2));
+      // size, tau 2); too short costs a second run of the search.  Option "hit_list_guess" overrides (tests).
+      size_t hit_cap = ctx->hit_guess > 0 ? (size_t)ctx->hit_guess
+                                          : std::max<size_t>((size_t)1 << 16, (size_t)R * (use_verify ? (size_t)tau + 4 : 2));
       HIP_TRY(hipEventRecord(b->ev[0], st));
+      b->attempts = 0;
       for (int attempt = 0; attempt < 2; attempt++) {
+         b->attempts = attempt + 1;
          HIP_TRY(b->hits.ensure(hit_cap * sizeof(Node)));
-         hit_cap = b->hits.cap / sizeof(Node);
-         HIP_TRY(hipMemsetAsync(cnt, 0, sizeof host_cnt, st));
+         if (!(ctx->hit_guess > 0 && attempt == 0)) hit_cap = b->hits.cap / sizeof(Node);      // (a guess given by option is taken as it is: tests)
+         HIP_TRY(hipMemsetAsync(cnt, 0, CNT_BYTES, st));
          SearchArgs A;
          A.ix = ctx->ix;
          A.reads = b->reads.as<const uint8_t>(); A.read_len = b->read_len.as<const uint16_t>();
-         A.len_row = b->len_row.as<const uint8_t>(); A.phases = b->phases.as<const uint32_t>();
+         A.len_row = b->len_row.as<const uint16_t>(); A.phases = b->phases.as<const uint32_t>();
          A.phase_rec = b->phase_rec.as<const uint2>(); A.n_rows = std::max(rows, 1);
          A.n_reads = R; A.stride = b->stride; A.tau = tau;
          A.cursor = cnt + 0; A.hits = b->hits.as<Node>(); A.hit_cap = hit_cap; A.hit_count = cnt + 1; A.n_ext = cnt + 2;
-         A.spill = ctx->spill.as<Node>(); A.spill_cap = (uint32_t)ctx->spill_cap; A.error = (int *)(cnt + 3); A.stats = cnt + 4;
+         A.spill = b->spill.as<Node>(); A.spill_cap = (uint32_t)ctx->spill_cap; A.error = (int *)(cnt + 3); A.stats = cnt + 4;
          A.jump = (const uint4 *)ctx->d_jump; A.jump_k = ctx->jump_k;
          A.verify = use_verify;
          {
@@ -685,7 +830,7 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
             hipLaunchKernelGGL(k_search, dim3((unsigned)n_wg), dim3(WG_THREADS), search_lds, st, A);
             HIP_TRY(hipGetLastError());
          }
-         HIP_TRY(hipMemcpyAsync(host_cnt, cnt, 64, hipMemcpyDeviceToHost, st));
+         HIP_TRY(hipMemcpyAsync(host_cnt, cnt, 8 * CNT_WORDS, hipMemcpyDeviceToHost, st));
          HIP_TRY(hipStreamSynchronize(st));
          GM_FAIL_IF(host_cnt[3] != 0, "search spill region overflowed (raise 'spill_nodes').");
          if (host_cnt[1] <= hit_cap) break;
@@ -696,6 +841,7 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
       const int pos_bits = ctx->ix.sar_bits;
       const int read_bits = bits_for((uint64_t)std::max<int64_t>(R, 1));
       GM_FAIL_IF(pos_bits + 4 + read_bits > 64, "batch too large for the 64-bit sort key (split the batch).");
+      b->key_pos_bits = pos_bits;
       HIP_TRY(hipEventRecord(b->ev[4], st));
       const bool verified = use_verify != 0 && host_cnt[1] > 0;
       if (verified) {
@@ -726,11 +872,11 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
             default: GM_VERIFY(4); break;
          }
 #undef GM_VERIFY
-         hipLaunchKernelGGL(k_sum_steps, dim3(64), dim3(256), 0, st, b->vsteps.as<const unsigned long long>(), (int64_t)vgrid.x, cnt + 8);
+         hipLaunchKernelGGL(k_sum_steps, dim3(64), dim3(256), 0, st, b->vsteps.as<const unsigned long long>(), (int64_t)vgrid.x, cnt + CNT_WORDS);
          HIP_TRY(hipGetLastError());
-         HIP_TRY(hipMemcpyAsync(host_cnt, cnt, sizeof host_cnt, hipMemcpyDeviceToHost, st));
+         HIP_TRY(hipMemcpyAsync(host_cnt, cnt, CNT_BYTES, hipMemcpyDeviceToHost, st));
          HIP_TRY(hipStreamSynchronize(st));
-         for (int k = 0; k < 64; k++) { host_cnt[2] += host_cnt[8 + k]; verify_steps += host_cnt[8 + k]; }
+         for (int k = 0; k < 64; k++) { host_cnt[2] += host_cnt[CNT_WORDS + k]; verify_steps += host_cnt[CNT_WORDS + k]; }
       }
       HIP_TRY(hipEventRecord(b->ev[1], st));
       b->n_hits = (int64_t)host_cnt[1];            // entries of the list, holes included
@@ -739,6 +885,7 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
       for (int i = 0; i < 4; i++) b->stats[i] = (int64_t)host_cnt[4 + i];
       b->stats[4] = (int64_t)verify_steps;
       b->stats[5] = (int64_t)host_cnt[1];
+      b->spill_chunks = (int64_t)host_cnt[8];
 
       // ---- K3 locate: slots per entry -> scan -> every entry fills its slots
       const int64_t H = b->n_hits;
@@ -755,10 +902,12 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
          }
          size_t tmp = 0;
          HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, b->hit_sizes.as<int64_t>(), b->hit_off.as<int64_t>(), (int)(H + 1), st));
-         HIP_TRY(ctx->cub_tmp.ensure(tmp));
-         HIP_TRY(hipcub::DeviceScan::ExclusiveSum(ctx->cub_tmp.p, tmp, b->hit_sizes.as<int64_t>(), b->hit_off.as<int64_t>(), (int)(H + 1), st));
-         HIP_TRY(hipMemcpyAsync(&L, b->hit_off.as<int64_t>() + H, 8, hipMemcpyDeviceToHost, st));
+         HIP_TRY(b->cub_tmp.ensure(tmp));
+         HIP_TRY(hipcub::DeviceScan::ExclusiveSum(b->cub_tmp.p, tmp, b->hit_sizes.as<int64_t>(), b->hit_off.as<int64_t>(), (int)(H + 1), st));
+         int64_t *h_L = reinterpret_cast<int64_t *>(host_cnt + CNT_WORDS + 64);
+         HIP_TRY(hipMemcpyAsync(h_L, b->hit_off.as<int64_t>() + H, 8, hipMemcpyDeviceToHost, st));
          HIP_TRY(hipStreamSynchronize(st));
+         L = *h_L;
       }
       b->n_locs = L;
       if (L > 0) {
@@ -767,7 +916,7 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
          HIP_TRY(b->keys_alt.ensure(8 * (size_t)L));
          const unsigned int longer_cap = (unsigned int)(L / PLACE_INLINE + 1);
          HIP_TRY(b->longer.ensure(4 * (size_t)longer_cap));
-         unsigned int *n_longer = (unsigned int *)(cnt + 8 + 64);
+         unsigned int *n_longer = (unsigned int *)(cnt + CNT_WORDS + 64);
          HIP_TRY(hipMemsetAsync(n_longer, 0, 8, st));
          hipLaunchKernelGGL(k_place, dim3((unsigned)cdiv(H, 256)), dim3(256), 0, st, ctx->ix, b->hits.as<const Node>(), H,
                             verified ? b->direct.as<const unsigned long long>() : (const unsigned long long *)nullptr,
@@ -785,15 +934,21 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
          hipcub::DoubleBuffer<unsigned long long> db(b->keys.as<unsigned long long>(), b->keys_alt.as<unsigned long long>());
          size_t tmp = 0;
          HIP_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp, db, (int)L, 0, pos_bits + 4 + read_bits, st));
-         HIP_TRY(ctx->cub_tmp.ensure(tmp));
-         HIP_TRY(hipcub::DeviceRadixSort::SortKeys(ctx->cub_tmp.p, tmp, db, (int)L, 0, pos_bits + 4 + read_bits, st));
-         for (DevBuf *x : {&b->loc_read, &b->loc_pos, &b->loc_fwd, &b->loc_seq, &b->loc_seqpos}) HIP_TRY(x->ensure(8 * (size_t)L));
-         HIP_TRY(b->loc_strand.ensure((size_t)L));
-         HIP_TRY(b->loc_score.ensure((size_t)L));
-         hipLaunchKernelGGL(k_unpack_locs, dim3((unsigned)cdiv(L, 256)), dim3(256), 0, st, ctx->ix,
-                            (const unsigned long long *)db.Current(), L, pos_bits, R, b->read_first.as<int64_t>(), b->loc_read.as<int64_t>(),
-                            b->loc_pos.as<int64_t>(), b->loc_fwd.as<int64_t>(), b->loc_seq.as<int64_t>(),
-                            b->loc_seqpos.as<int64_t>(), b->loc_strand.as<uint8_t>(), b->loc_score.as<uint8_t>());
+         HIP_TRY(b->cub_tmp.ensure(tmp));
+         HIP_TRY(hipcub::DeviceRadixSort::SortKeys(b->cub_tmp.p, tmp, db, (int)L, 0, pos_bits + 4 + read_bits, st));
+         b->sorted_keys = db.Current();
+         if (compact) {
+            hipLaunchKernelGGL(k_read_first, dim3((unsigned)cdiv(L, 256)), dim3(256), 0, st, b->sorted_keys, L, pos_bits, R,
+                               b->read_first.as<int64_t>());
+         } else {
+            for (DevBuf *x : {&b->loc_read, &b->loc_pos, &b->loc_fwd, &b->loc_seq, &b->loc_seqpos}) HIP_TRY(x->ensure(8 * (size_t)L));
+            HIP_TRY(b->loc_strand.ensure((size_t)L));
+            HIP_TRY(b->loc_score.ensure((size_t)L));
+            hipLaunchKernelGGL(k_unpack_locs, dim3((unsigned)cdiv(L, 256)), dim3(256), 0, st, ctx->ix,
+                               b->sorted_keys, L, pos_bits, R, b->read_first.as<int64_t>(), b->loc_read.as<int64_t>(),
+                               b->loc_pos.as<int64_t>(), b->loc_fwd.as<int64_t>(), b->loc_seq.as<int64_t>(),
+                               b->loc_seqpos.as<int64_t>(), b->loc_strand.as<uint8_t>(), b->loc_score.as<uint8_t>());
+         }
          HIP_TRY(hipGetLastError());
       }
       if (want_intervals && H > 0) {
@@ -807,8 +962,8 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
          hipcub::DoubleBuffer<unsigned int> dv(b->hidx.as<unsigned int>(), b->hidx_alt.as<unsigned int>());
          size_t tmp = 0;
          HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, dk, dv, (int)H, 0, 64, st));
-         HIP_TRY(ctx->cub_tmp.ensure(tmp));
-         HIP_TRY(hipcub::DeviceRadixSort::SortPairs(ctx->cub_tmp.p, tmp, dk, dv, (int)H, 0, 64, st));
+         HIP_TRY(b->cub_tmp.ensure(tmp));
+         HIP_TRY(hipcub::DeviceRadixSort::SortPairs(b->cub_tmp.p, tmp, dk, dv, (int)H, 0, 64, st));
          for (DevBuf *x : {&b->hit_read, &b->hit_fp, &b->hit_rp, &b->hit_sz, &b->hit_dp, &b->hit_score}) HIP_TRY(x->ensure(8 * (size_t)H));
          HIP_TRY(b->hit_align.ensure(32 * (size_t)H));
          // the holes of the list sorted last: the first n_real entries are the hits
@@ -825,6 +980,7 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
       HIP_TRY(hipEventElapsedTime(&b->ms[1], b->ev[1], b->ev[2]));
       HIP_TRY(hipEventElapsedTime(&b->ms[2], b->ev[2], b->ev[3]));
       HIP_TRY(hipEventElapsedTime(&b->ms[3], b->ev[0], b->ev[3]));
+      HIP_TRY(hipEventElapsedTime(&b->ms_encode, b->ev[5], b->ev[0]));
       {
          float ms_k = 0, ms_v = 0;
          HIP_TRY(hipEventElapsedTime(&ms_k, b->ev[0], b->ev[4]));
@@ -835,6 +991,19 @@ extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int w
       b->ran = true;
    }
    return 0;
+failure_return:
+   return -1;
+}
+
+static int result_flags_of(const gpumap_ctx *ctx)
+{
+   return (ctx->pinned_results ? GM_RESULT_PINNED : 0) | (ctx->compact_results ? GM_RESULT_COMPACT : 0);
+}
+
+extern "C" int gpumap_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals)
+{
+   GM_FAIL_IF(ctx == nullptr || b == nullptr, "NULL argument.");
+   return gm_batch_run(ctx, b, tau, want_intervals, result_flags_of(ctx));
 failure_return:
    return -1;
 }
@@ -862,6 +1031,21 @@ failure_return:
    return -1;
 }
 
+extern "C" int gpumap_batch_stats_ext(const gpumap_batch *b, int64_t stats[8])
+{
+   GM_FAIL_IF(b == nullptr || stats == nullptr, "NULL argument.");
+   GM_FAIL_IF(!b->ran, "batch has not been run.");
+   stats[0] = b->attempts;
+   stats[1] = (int64_t)(1000.0f * b->ms_encode);
+   stats[2] = b->compact ? 1 : 0;
+   stats[3] = (int64_t)(b->hits.cap / sizeof(Node));
+   stats[4] = b->spill_chunks;
+   stats[5] = stats[6] = stats[7] = 0;
+   return 0;
+failure_return:
+   return -1;
+}
+
 extern "C" void *gpumap_host_alloc(size_t bytes)
 {
    void *p = nullptr;
@@ -880,14 +1064,16 @@ extern "C" void gpumap_hits_free(gpumap_hits *h)
    if (!h) return;
    if (!h->arena) {
       free(h->status); free(h->read_first_loc); free(h->loc_read); free(h->loc_pos); free(h->loc_fwd); free(h->loc_seq);
-      free(h->loc_seqpos); free(h->loc_strand); free(h->loc_score);
+      free(h->loc_seqpos); free(h->loc_strand); free(h->loc_score); free(h->loc_key);
       free(h->hit_read); free(h->hit_fp); free(h->hit_rp); free(h->hit_sz); free(h->hit_dp); free(h->hit_score); free(h->hit_align);
+   } else if (h->expanded) {          // gpumap_hits_expand malloc'ed these beside an arena-backed result
+      free(h->loc_read); free(h->loc_pos); free(h->loc_fwd); free(h->loc_seq); free(h->loc_seqpos); free(h->loc_strand); free(h->loc_score);
    }
    memset(h, 0, sizeof *h);
 }
 
 namespace {
-// Destination of one fetch: malloc'ed arrays, or slices of the context's page-locked arena.
+// Destination of one fetch: malloc'ed arrays, or slices of a page-locked arena of the batch.
 struct FetchDst {
    char *arena = nullptr;
    size_t used = 0;
@@ -901,59 +1087,66 @@ struct FetchDst {
    }
 };
 template <class T>
-int fetch_array(FetchDst &d, T **dst, const DevBuf &src, int64_t count, hipStream_t st)
+int fetch_array(FetchDst &d, T **dst, const void *src, int64_t count, hipStream_t st)
 {
    *dst = d.take<T>(count);
    if (!*dst) return -1;
-   if (count > 0 && hipMemcpyAsync(*dst, src.p, sizeof(T) * (size_t)count, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
+   if (count > 0 && hipMemcpyAsync(*dst, src, sizeof(T) * (size_t)count, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
    return 0;
 }
 }  // namespace
 
-extern "C" int gpumap_batch_fetch(gpumap_ctx *ctx, gpumap_batch *b, gpumap_hits *out)
+int gm_batch_fetch(gpumap_ctx *ctx, gpumap_batch *b, gpumap_hits *out, int result_flags)
 {
    GM_FAIL_IF(ctx == nullptr || b == nullptr || out == nullptr, "NULL argument.");
    GM_FAIL_IF(!b->ran, "batch has not been run.");
    memset(out, 0, sizeof *out);
    HIP_TRY(hipSetDevice(ctx->device));
    {
-      hipStream_t st = ctx->stream;
+      hipStream_t st = b->stream;
       const int64_t R = b->n_reads, L = b->n_locs, H = b->have_intervals ? b->n_real : 0;
+      const bool compact = b->compact;               // what the run left on the device decides
       FetchDst d;
-      if (ctx->pinned_results) {
-         size_t need = 16 * 256 + 8 * (size_t)(2 * R + 1) + 42 * (size_t)L + 80 * (size_t)H;
-         // two arenas in turn: what a fetch hands out stays valid until the fetch after the next one
-         const int k = ctx->pin_turn;
-         ctx->pin_turn ^= 1;
-         if (need > ctx->pin_cap[k]) {
-            if (ctx->pin_arena[k]) { HIP_TRY(hipHostFree(ctx->pin_arena[k])); ctx->pin_arena[k] = nullptr; ctx->pin_cap[k] = 0; }
+      if (result_flags & GM_RESULT_PINNED) {
+         size_t need = 16 * 256 + 8 * (size_t)(2 * R + 1) + (compact ? 8 : 42) * (size_t)L + 80 * (size_t)H;
+         // two arenas in turn: what a fetch hands out stays valid until the fetch after the next one on this batch
+         // (the pipeline releases a slot's result before the slot is used again: one arena there)
+         const int k = (result_flags & GM_RESULT_ONE_ARENA) ? 0 : b->pin_turn;
+         b->pin_turn ^= 1;
+         if (need > b->pin_cap[k]) {
+            if (b->pin_arena[k]) { HIP_TRY(hipHostFree(b->pin_arena[k])); b->pin_arena[k] = nullptr; b->pin_cap[k] = 0; }
             need += need / 4;
-            HIP_TRY(hipHostMalloc(&ctx->pin_arena[k], need, hipHostMallocDefault));
-            ctx->pin_cap[k] = need;
+            HIP_TRY(hipHostMalloc(&b->pin_arena[k], need, hipHostMallocDefault));
+            b->pin_cap[k] = need;
          }
-         d.arena = (char *)ctx->pin_arena[k];
-         out->arena = ctx->pin_arena[k];
+         d.arena = (char *)b->pin_arena[k];
+         out->arena = b->pin_arena[k];
       }
       out->n_reads = R; out->n_locs = L; out->n_hits = H; out->n_ext = b->n_ext;
       out->ms_search = b->ms[0]; out->ms_locate = b->ms[1]; out->ms_sort = b->ms[2]; out->ms_total = b->ms[3];
+      out->key_pos_bits = b->key_pos_bits;
       int rc = 0;
-      rc |= fetch_array(d, &out->status, b->status, R, st);
-      rc |= fetch_array(d, &out->read_first_loc, b->read_first, R + 1, st);
-      rc |= fetch_array(d, &out->loc_read, b->loc_read, L, st);
-      rc |= fetch_array(d, &out->loc_pos, b->loc_pos, L, st);
-      rc |= fetch_array(d, &out->loc_fwd, b->loc_fwd, L, st);
-      rc |= fetch_array(d, &out->loc_seq, b->loc_seq, L, st);
-      rc |= fetch_array(d, &out->loc_seqpos, b->loc_seqpos, L, st);
-      rc |= fetch_array(d, &out->loc_strand, b->loc_strand, L, st);
-      rc |= fetch_array(d, &out->loc_score, b->loc_score, L, st);
+      rc |= fetch_array(d, &out->status, b->status.p, R, st);
+      rc |= fetch_array(d, &out->read_first_loc, b->read_first.p, R + 1, st);
+      if (compact) {
+         rc |= fetch_array(d, &out->loc_key, (const void *)b->sorted_keys, L, st);
+      } else {
+         rc |= fetch_array(d, &out->loc_read, b->loc_read.p, L, st);
+         rc |= fetch_array(d, &out->loc_pos, b->loc_pos.p, L, st);
+         rc |= fetch_array(d, &out->loc_fwd, b->loc_fwd.p, L, st);
+         rc |= fetch_array(d, &out->loc_seq, b->loc_seq.p, L, st);
+         rc |= fetch_array(d, &out->loc_seqpos, b->loc_seqpos.p, L, st);
+         rc |= fetch_array(d, &out->loc_strand, b->loc_strand.p, L, st);
+         rc |= fetch_array(d, &out->loc_score, b->loc_score.p, L, st);
+      }
       if (b->have_intervals) {
-         rc |= fetch_array(d, &out->hit_read, b->hit_read, H, st);
-         rc |= fetch_array(d, &out->hit_fp, b->hit_fp, H, st);
-         rc |= fetch_array(d, &out->hit_rp, b->hit_rp, H, st);
-         rc |= fetch_array(d, &out->hit_sz, b->hit_sz, H, st);
-         rc |= fetch_array(d, &out->hit_dp, b->hit_dp, H, st);
-         rc |= fetch_array(d, &out->hit_score, b->hit_score, H, st);
-         rc |= fetch_array(d, &out->hit_align, b->hit_align, 4 * H, st);
+         rc |= fetch_array(d, &out->hit_read, b->hit_read.p, H, st);
+         rc |= fetch_array(d, &out->hit_fp, b->hit_fp.p, H, st);
+         rc |= fetch_array(d, &out->hit_rp, b->hit_rp.p, H, st);
+         rc |= fetch_array(d, &out->hit_sz, b->hit_sz.p, H, st);
+         rc |= fetch_array(d, &out->hit_dp, b->hit_dp.p, H, st);
+         rc |= fetch_array(d, &out->hit_score, b->hit_score.p, H, st);
+         rc |= fetch_array(d, &out->hit_align, b->hit_align.p, 4 * H, st);
       }
       HIP_TRY(hipStreamSynchronize(st));
       GM_FAIL_IF(rc != 0, "memory error.");
@@ -964,12 +1157,66 @@ failure_return:
    return -1;
 }
 
+extern "C" int gpumap_batch_fetch(gpumap_ctx *ctx, gpumap_batch *b, gpumap_hits *out)
+{
+   GM_FAIL_IF(ctx == nullptr || b == nullptr || out == nullptr, "NULL argument.");
+   return gm_batch_fetch(ctx, b, out, result_flags_of(ctx));
+failure_return:
+   return -1;
+}
+
+// The structure of arrays of a compact result, derived on the host from the sorted keys by the rule of
+// txt_pos_to_str (src/index_txt.c:492-505) and seq_bisect (:770-787): what k_unpack_locs computes on the device.
+extern "C" int gpumap_hits_expand(const gpumap_ctx *ctx, gpumap_hits *h)
+{
+   GM_FAIL_IF(ctx == nullptr || h == nullptr, "NULL argument.");
+   if (h->loc_key == nullptr || h->loc_read != nullptr) return 0;       // nothing to do
+   {
+      const int64_t L = h->n_locs, n = ctx->ix.n;
+      const int bits = h->key_pos_bits;
+      const size_t cnt = (size_t)std::max<int64_t>(L, 1);
+      h->loc_read = (int64_t *)malloc(8 * cnt); h->loc_pos = (int64_t *)malloc(8 * cnt); h->loc_fwd = (int64_t *)malloc(8 * cnt);
+      h->loc_seq = (int64_t *)malloc(8 * cnt); h->loc_seqpos = (int64_t *)malloc(8 * cnt);
+      h->loc_strand = (uint8_t *)malloc(cnt); h->loc_score = (uint8_t *)malloc(cnt);
+      h->expanded = 1;
+      GM_FAIL_IF(!h->loc_read || !h->loc_pos || !h->loc_fwd || !h->loc_seq || !h->loc_seqpos || !h->loc_strand || !h->loc_score, "memory error.");
+      const std::vector<int64_t> &beg = ctx->seq_beg_host;
+      const int T = gm_host_threads();
+      gm_parallel_for(T, [&](int t) {
+         for (int64_t i = L * t / T; i < L * (t + 1) / T; i++) {
+            const uint64_t k = h->loc_key[i];
+            const int64_t pos = GPUMAP_KEY_POS(k, bits);
+            const int strand = pos >= n / 2;
+            const int64_t f = strand ? n - 2 - pos : pos;
+            int64_t lo = 0, hi = (int64_t)beg.size();
+            while (hi - lo >= 2) { const int64_t mid = (lo + hi) / 2; if (f < beg[(size_t)mid]) hi = mid; else lo = mid; }
+            h->loc_read[i] = GPUMAP_KEY_READ(k, bits); h->loc_pos[i] = pos; h->loc_score[i] = (uint8_t)GPUMAP_KEY_SCORE(k);
+            h->loc_strand[i] = (uint8_t)strand; h->loc_fwd[i] = f; h->loc_seq[i] = lo; h->loc_seqpos[i] = f - beg[(size_t)lo] + 1;
+         }
+      });
+   }
+   return 0;
+failure_return:
+   return -1;
+}
+
 extern "C" int gpumap_map_batch(gpumap_ctx *ctx, const uint8_t *codes, const int64_t *offsets, int64_t n_reads,
                                 int tau, int want_intervals, gpumap_hits *out)
 {
    gpumap_batch *b = nullptr;
    GM_FAIL_IF(out == nullptr, "argument 'out' is NULL.");
    memset(out, 0, sizeof *out);
+   GM_FAIL_IF(ctx == nullptr, "argument 'ctx' is NULL.");
+   if (ctx->pinned_results) {
+      // the arenas belong to a batch: one batch that lives as long as the context serves these calls
+      if (ctx->map_batch_obj == nullptr) ctx->map_batch_obj = gpumap_batch_new(ctx);
+      b = ctx->map_batch_obj;
+      GM_FAIL_IF(b == nullptr, "cannot create the batch.");
+      GM_FAIL_IF(gm_batch_fill(ctx, b, codes, offsets, n_reads, 0, true) != 0, "cannot upload the batch.");
+      GM_FAIL_IF(gpumap_batch_run(ctx, b, tau, want_intervals) != 0, "batch failed.");
+      GM_FAIL_IF(gpumap_batch_fetch(ctx, b, out) != 0, "cannot fetch results.");
+      return 0;
+   }
    b = gpumap_batch_upload(ctx, codes, offsets, n_reads);
    GM_FAIL_IF(b == nullptr, "cannot upload the batch.");
    GM_FAIL_IF(gpumap_batch_run(ctx, b, tau, want_intervals) != 0, "batch failed.");
@@ -977,7 +1224,6 @@ extern "C" int gpumap_map_batch(gpumap_ctx *ctx, const uint8_t *codes, const int
    gpumap_batch_free(b);
    return 0;
 failure_return:
-   gpumap_batch_free(b);
+   if (ctx == nullptr || b != ctx->map_batch_obj) gpumap_batch_free(b);
    return -1;
 }
-

@@ -87,3 +87,11 @@ void gm_reads_close(gm_read_stream *s);
 // fn(t) for t = 0..threads-1 on as many threads (the caller's among them); returns when all are done.
 void gm_parallel_for(int threads, const std::function<void(int)> &fn);
 int gm_host_threads();     // worker threads of the host stages: GPUMAP_HOST_THREADS, else min(16, cores)
+
+// Internal forms of the batch calls (gm_device.hip), used by the pipeline (gm_pipe.cpp): the public entry points
+// derive the flags from the context's options, the pipeline brings its own.
+constexpr int GM_RESULT_PINNED = 1, GM_RESULT_COMPACT = 2, GM_RESULT_ONE_ARENA = 4;
+constexpr int GM_SRC_TEXT = GPUMAP_SRC_TEXT, GM_SRC_DEVICE = GPUMAP_SRC_DEVICE;
+int gm_batch_fill(gpumap_ctx *ctx, gpumap_batch *b, const void *src, const int64_t *offsets, int64_t n_reads, int src_flags, bool encode_now);
+int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, int result_flags);
+int gm_batch_fetch(gpumap_ctx *ctx, gpumap_batch *b, gpumap_hits *out, int result_flags);

@@ -20,6 +20,7 @@ constexpr int WG_WAVES = 4;
 constexpr int WG_THREADS = 64 * WG_WAVES;
 constexpr int QCAP = 128;            // deque capacity per wave (nodes), power of two
 constexpr int SPILL_CHUNK = 64;      // nodes moved per spill / reload
+constexpr uint16_t NO_ROW = 0xffff;  // len_row[m]: the reference returns -1 for reads of m letters (src/blocksearch.c:126)
 
 // ------------------------------------------------------------------------------------------------
 // K0: repack
@@ -178,21 +179,41 @@ __global__ void k_sar_get(IndexDev ix, int64_t n, const int64_t *pos, int64_t *o
 // ------------------------------------------------------------------------------------------------
 // K4: reads.  Letters (or codes) -> codes in a fixed-stride matrix [n_reads][stride].
 // ------------------------------------------------------------------------------------------------
-__global__ void k_encode(const uint8_t *src, const int64_t *offsets, int64_t n_reads, int stride,
-                         const uint8_t *table /* 256 entries, or nullptr for codes */, uint8_t *dst,
-                         uint16_t *read_len, uint8_t *flat_codes /* optional, same layout as src */)
+// Lengths of the reads of a batch from its offsets (device memory): read_len[r], and which lengths occur
+// (seen[len] = 1 for len <= MAX_READ, seen[MAX_READ + 1] = 1 for longer reads, seen[MAX_READ + 2] = 1 when an
+// offset decreases).  The host builds one phase-table row per length from `seen` and sizes the read matrix by
+// the longest; no loop over the reads on the host.  One store per workgroup and length (LDS flags first).
+constexpr int SEEN_LONGER = MAX_READ + 1, SEEN_ERROR = MAX_READ + 2, SEEN_BYTES = 264;
+__global__ void __launch_bounds__(256) k_read_lengths(const int64_t *offsets, int64_t n_reads, uint16_t *read_len, uint8_t *seen)
 {
+   __shared__ uint32_t s_seen[SEEN_BYTES];
+   for (int i = threadIdx.x; i < SEEN_BYTES; i += blockDim.x) s_seen[i] = 0;
+   __syncthreads();
+   for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n_reads; r += (int64_t)gridDim.x * blockDim.x) {
+      const int64_t len = offsets[r + 1] - offsets[r];
+      read_len[r] = (uint16_t)(len < 0 ? 0 : (len > 0xffff ? 0xffff : len));
+      s_seen[len < 0 ? SEEN_ERROR : (len > MAX_READ ? SEEN_LONGER : (int)len)] = 1;
+   }
+   __syncthreads();
+   for (int i = threadIdx.x; i < SEEN_BYTES; i += blockDim.x)
+      if (s_seen[i]) seen[i] = 1;
+}
+
+__global__ void k_encode(const uint8_t *src, const int64_t *offsets, int relative, int64_t n_reads, int stride,
+                         const uint8_t *table /* 256 entries, or nullptr for codes */, uint8_t *dst)
+{
+   // src holds the letters of the batch: at offsets[r] (relative = 0: the caller's device buffer), or at
+   // offsets[r] - offsets[0] (relative = 1: the library's copy of the part of a host buffer the batch uses).
    // grid-stride: a launch holds fewer than 2^32 threads, a batch may hold more letters
+   const int64_t sub = relative ? offsets[0] : 0;
    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n_reads * stride; t += (int64_t)gridDim.x * blockDim.x) {
       int64_t r = t / stride;
       int p = (int)(t - r * stride);
       int64_t beg = offsets[r], len = offsets[r + 1] - beg;
-      if (p == 0) read_len[r] = (uint16_t)(len < 0 ? 0 : (len > 0xffff ? 0xffff : len));
       uint8_t code = 0xff;
       if (p < len) {
-         uint8_t s = src[beg + p];
+         uint8_t s = src[beg - sub + p];
          code = table ? table[s] : (s < SYMS ? s : (uint8_t)UNKNOWN);
-         if (flat_codes) flat_codes[beg + p] = code;
       }
       dst[t] = code;
    }
@@ -245,7 +266,7 @@ struct SearchArgs {
    IndexDev ix;
    const uint8_t  *reads;       // [n_reads][stride] codes
    const uint16_t *read_len;    // [n_reads]
-   const uint8_t  *len_row;     // [MAX_READ + 1] -> row of `phases`, 0xff = the reference returns -1
+   const uint16_t *len_row;     // [MAX_READ + 1] -> row of `phases`, NO_ROW = the reference returns -1
    const uint32_t *phases;      // [rows][MAX_PHASES]
    const uint2    *phase_rec;   // [rows][MAX_PHASES] what a node becomes at the end of a phase (phase_record)
    int n_rows;
@@ -260,7 +281,8 @@ struct SearchArgs {
    uint32_t spill_cap;
    int *error;                  // set to 1 when a spill region overflows
    unsigned long long *stats;   // [0] passes of the main loop over all waves, [1] continuations pushed,
-                                // [2] extension steps the jump table stood in for, [3] entries of the list that are not holes
+                                // [2] extension steps the jump table stood in for, [3] entries of the list that are not holes,
+                                // [4] chunks of SPILL_CHUNK nodes that deques moved to their spill regions
    const uint4 *jump;           // jump table (k_build_jump) or nullptr
    int jump_k;
    int verify;                  // nodes with sz <= verify (0, 1 or 2) leave as candidates for k_verify
@@ -637,6 +659,7 @@ struct WaveQueue {
    Node *q;
    Node *spill;
    uint32_t bot, top, spill_top, spill_cap;
+   uint32_t n_spilled;        // chunks this wave moved to its spill region
    int *error;
 };
 
@@ -656,6 +679,7 @@ __device__ __forceinline__ void wave_push(WaveQueue &wq, bool flag, const Node &
             d[1] = make_uint4(t.w[4], t.w[5], t.w[6], t.w[7]);
          }
          wq.spill_top += CHUNK;
+         wq.n_spilled++;
       } else if (lane == 0) {
          *wq.error = 1;      // results are incomplete; the host reports the failure
       }
@@ -791,12 +815,26 @@ __global__ void k_unpack_hits(const Node *hits, const unsigned int *idx, int64_t
    for (int w = 0; w < 4; w++) hit_align_out[4 * i + w] = al[w];
 }
 
-__global__ void k_status(const uint16_t *read_len, const uint8_t *len_row, int64_t n_reads, int64_t *status)
+__global__ void k_status(const uint16_t *read_len, const uint16_t *len_row, int64_t n_reads, int64_t *status)
 {
    int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
    if (r >= n_reads) return;
    int m = read_len[r];
-   status[r] = (m <= MAX_READ && len_row[m] != 0xff) ? 0 : -1;
+   status[r] = (m <= MAX_READ && len_row[m] != NO_ROW) ? 0 : -1;
+}
+
+// Compact results: the sorted keys are the output; only the CSR offsets of the reads are derived from them
+// (as k_unpack_locs does: the thread of the first key of a read writes that read's offset and those of the
+// reads without hits before it).
+__global__ void k_read_first(const unsigned long long *keys, int64_t n_locs, int pos_bits, int64_t n_reads, int64_t *read_first)
+{
+   int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+   if (t >= n_locs) return;
+   const int64_t read = (int64_t)(keys[t] >> (pos_bits + 4));
+   const int64_t before = t == 0 ? -1 : (int64_t)(keys[t - 1] >> (pos_bits + 4));
+   for (int64_t r = before + 1; r <= read; r++) read_first[r] = t;
+   if (t == n_locs - 1)
+      for (int64_t r = read + 1; r <= n_reads; r++) read_first[r] = n_locs;
 }
 
 }  // namespace gm

@@ -1,9 +1,10 @@
 // gm_mapper.cpp -- mapper() (src/mapper.c:3-47): chunks of reads -> GPU batches -> one line per located
-// hit.  The reference's loop (read a chunk, work on it, print, next chunk; src/mapper.c:23-40) as three
-// stages that overlap: a reader thread cuts and parses chunk i+1 (gm_reads.cpp), the calling thread
-// maps chunk i on the GPU through the C-ABI of gpumap.h (one batch object, refilled), a writer thread
-// formats and writes chunk i-1 (txt_pos_to_str's "name:pos:strand", src/index_txt.c:480-511, from the
-// sequence id / position / strand the device computed).  Host code only: no HIP in this file.
+// hit.  The reference's loop (read a chunk, work on it, print, next chunk; src/mapper.c:23-40) as stages
+// that overlap: a reader thread cuts and parses the chunks (gm_reads.cpp) and hands them to a gpumap_pipe
+// (gm_pipe.cpp: copy to the device, search, copy of the results back, each chunk on a slot with a stream of
+// its own, over one or several GPUs), the calling thread takes the results in input order, formats and writes
+// them (txt_pos_to_str's "name:pos:strand", src/index_txt.c:480-511, from the compact keys: strand and
+// coordinates by the rule of :492-505 with seq_bisect :770-787).  Host code only: no HIP in this file.
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -82,33 +83,43 @@ inline char *put_num(char *p, int64_t v)
    return p;
 }
 
-// "tag \t name:pos:strand \t score \n" for the located hits [lo, hi) of a chunk.
+// "tag \t name:pos:strand \t score \n" for the located hits [lo, hi) of a chunk (compact results: sorted keys).
 void format_range(const Job &j, const gpumap_index_view &v, const std::vector<size_t> &name_len, int64_t lo, int64_t hi,
                   std::vector<char> &out)
 {
    const gpumap_hits &h = j.h;
+   const int bits = h.key_pos_bits;
+   const int64_t n = v.txt_len;
+   size_t max_name = 0;
+   for (size_t l : name_len) max_name = std::max(max_name, l);
    size_t need = 0;
    char num[32];
    for (int64_t t = lo; t < hi; t++) {
       size_t tl;
-      (void)j.chunk.tag((size_t)h.loc_read[t], num, &tl);
-      need += tl + name_len[(size_t)h.loc_seq[t]] + 32;
+      (void)j.chunk.tag((size_t)GPUMAP_KEY_READ(h.loc_key[t], bits), num, &tl);
+      need += tl + max_name + 32;
    }
    out.resize(need);
    char *p = out.data();
    for (int64_t t = lo; t < hi; t++) {
+      const uint64_t k = h.loc_key[t];
+      const int64_t pos = GPUMAP_KEY_POS(k, bits);
+      const bool minus = pos >= n / 2;                                  // src/index_txt.c:492-496
+      const int64_t f = minus ? n - 2 - pos : pos;
+      int64_t a = 0, e = v.seq_cnt;                                     // seq_bisect, src/index_txt.c:770-787
+      while (e - a >= 2) { const int64_t mid = (a + e) / 2; if (f < v.seq_beg[mid]) e = mid; else a = mid; }
       size_t tl;
-      const char *tag = j.chunk.tag((size_t)h.loc_read[t], num, &tl);
+      const char *tag = j.chunk.tag((size_t)GPUMAP_KEY_READ(k, bits), num, &tl);
       memcpy(p, tag, tl); p += tl;
       *p++ = '\t';
-      const size_t nl = name_len[(size_t)h.loc_seq[t]];
-      memcpy(p, v.seq_name[h.loc_seq[t]], nl); p += nl;
+      const size_t nl = name_len[(size_t)a];
+      memcpy(p, v.seq_name[a], nl); p += nl;
       *p++ = ':';
-      p = put_num(p, h.loc_seqpos[t]);
+      p = put_num(p, f - v.seq_beg[a] + 1);
       *p++ = ':';
-      *p++ = h.loc_strand[t] ? '-' : '+';
+      *p++ = minus ? '-' : '+';
       *p++ = '\t';
-      p = put_num(p, (int64_t)h.loc_score[t]);
+      p = put_num(p, (int64_t)GPUMAP_KEY_SCORE(k));
       *p++ = '\n';
    }
    out.resize((size_t)(p - out.data()));
@@ -127,20 +138,20 @@ int write_all(int fd, const char *p, size_t n, int64_t at /* -1: at the file pos
 
 }  // namespace
 
-extern "C" int gpumap_mapper(const char *qfile, const gpumap_index *index, gpumap_ctx *ctx, int tau, const char *out_path)
+static int mapper_run(const char *qfile, const gpumap_index *index, gpumap_ctx *const *ctxs, int n_ctx, int tau, const char *out_path)
 {
    gm_read_stream *in = nullptr;
    int fo = -1;
    bool fo_regular = false, fo_own = false;
    int64_t fo_off = 0;
-   gpumap_batch *b = nullptr;
-   Chan to_gpu(2), to_writer(1), spare(4);      // spare: chunk objects go round, their buffers are allocated once
-   std::thread reader, writer;
+   gpumap_pipe *pipe = nullptr;
+   Chan spare(256);              // chunk objects go round, their buffers are allocated once
+   std::thread reader;
    int reader_rc = 0, writer_rc = 0;
    bool failed = false;
    GM_FAIL_IF(qfile == nullptr, "argument 'qfile' is NULL.");
    GM_FAIL_IF(index == nullptr, "argument 'index' is NULL.");
-   GM_FAIL_IF(ctx == nullptr, "argument 'ctx' is NULL.");
+   GM_FAIL_IF(ctxs == nullptr || n_ctx < 1 || ctxs[0] == nullptr, "argument 'ctx' is NULL.");
    in = gm_reads_open(qfile);
    GM_FAIL_IF(in == nullptr, "cannot open the read file.");
    if (out_path == nullptr || !strcmp(out_path, "-")) {
@@ -153,18 +164,22 @@ extern "C" int gpumap_mapper(const char *qfile, const gpumap_index *index, gpuma
       struct stat sb;
       fo_regular = fstat(fo, &sb) == 0 && S_ISREG(sb.st_mode);       // its parts can be written side by side
    }
-   GM_FAIL_IF(gpumap_set_option(ctx, "pinned_results", 1) != 0, "cannot set up the result buffers.");
    {
+      // per GPU: one chunk on its way in, one being searched, one on its way out or being written
+      const int depth = 3;
+      pipe = gpumap_pipe_create(ctxs, n_ctx, depth, tau, GPUMAP_SRC_TEXT | GPUMAP_PIPE_COMPACT);
+      GM_FAIL_IF(pipe == nullptr, "cannot set up the pipeline.");
       const gpumap_index_view &v = index->view;
       std::vector<size_t> name_len((size_t)v.seq_cnt);
       for (int64_t i = 0; i < v.seq_cnt; i++) name_len[(size_t)i] = strlen(v.seq_name[i]);
       size_t chunk_bytes = (size_t)256 << 20;                     // IO_DEFAULT_BUFSIZE, src/io.h:13
       if (const char *e = getenv("GPUMAP_CHUNK_BYTES")) chunk_bytes = (size_t)std::max<long long>(1, atoll(e));
       const int T = gm_host_threads();
-      double t_read = 0, t_parse = 0, t_upload = 0, t_run = 0, t_fetch = 0, t_format = 0, t_write = 0, t_wait = 0;
+      double t_read = 0, t_parse = 0, t_format = 0, t_write = 0, t_wait = 0;
       const double t_begin = now_s();
+      const int n_jobs = depth * n_ctx + 2;
 
-      for (int i = 0; i < 4; i++) {
+      for (int i = 0; i < n_jobs; i++) {
          Job *j = new Job();
          j->chunk.text.pinned = true;                             // uploaded from where the parser writes it
          spare.push(j);
@@ -177,82 +192,87 @@ extern "C" int gpumap_mapper(const char *qfile, const gpumap_index *index, gpuma
             j->n = gm_reads_next(in, chunk_bytes, &j->chunk);
             t_read += j->chunk.t_read; t_parse += j->chunk.t_parse;
             if (j->n <= 0) { reader_rc = j->n < 0 ? -1 : 0; delete j; break; }
-            if (!to_gpu.push(j)) { delete j; break; }
+            fprintf(stderr, "read: %ld sequences.\n", (long)j->n);                 // src/mapper.c:30
+            if (gpumap_pipe_submit(pipe, j->chunk.text.data(), j->chunk.offsets.data(), j->n, j) != 0) { delete j; reader_rc = -1; break; }
          }
-         to_gpu.close();
-      });
-      writer = std::thread([&] {
-         std::vector<std::vector<char>> parts((size_t)T);
-         while (Job *j = to_writer.pop()) {
-            const int64_t L = j->h.n_locs;
-            const double w0 = now_s();
-            gm_parallel_for(T, [&](int t) { format_range(*j, v, name_len, L * t / T, L * (t + 1) / T, parts[(size_t)t]); });
-            const double w1 = now_s();
-            if (fo_regular) {
-               std::vector<int64_t> at((size_t)T + 1, fo_off);
-               for (int t = 0; t < T; t++) at[(size_t)t + 1] = at[(size_t)t] + (int64_t)parts[(size_t)t].size();
-               std::vector<int> bad((size_t)T, 0);
-               gm_parallel_for(T, [&](int t) {
-                  const auto &part = parts[(size_t)t];
-                  if (!part.empty() && write_all(fo, part.data(), part.size(), at[(size_t)t]) != 0) bad[(size_t)t] = 1;
-               });
-               for (int x : bad) if (x) writer_rc = -1;
-               fo_off = at[(size_t)T];
-            } else {
-               for (auto &part : parts)
-                  if (!part.empty() && write_all(fo, part.data(), part.size(), -1) != 0) writer_rc = -1;
-            }
-            t_format += w1 - w0; t_write += now_s() - w1;
-            gpumap_hits_free(&j->h);
-            if (!spare.push(j)) delete j;
-            if (writer_rc != 0) { to_writer.close(); break; }
-         }
+         gpumap_pipe_close(pipe);
       });
 
-      while (Job *j = to_gpu.pop()) {
-         fprintf(stderr, "read: %ld sequences.\n", (long)j->n);                 // src/mapper.c:30
-         int rc = 0;
-         const double g0 = now_s();
-         if (b == nullptr) {
-            b = gpumap_batch_upload_text(ctx, j->chunk.text.data(), j->chunk.offsets.data(), j->n);
-            rc = b == nullptr ? -1 : 0;
+      std::vector<std::vector<char>> parts((size_t)T);
+      for (;;) {
+         gpumap_hits h;
+         void *user = nullptr;
+         const double w_1 = now_s();
+         const int got = gpumap_pipe_next(pipe, &h, &user);
+         Job *j = (Job *)user;
+         if (got == 0) break;
+         if (got < 0) { failed = true; if (j && !spare.push(j)) delete j; break; }
+         j->h = h;
+         const int64_t L = h.n_locs;
+         const double w0 = now_s();
+         gm_parallel_for(T, [&](int t) { format_range(*j, v, name_len, L * t / T, L * (t + 1) / T, parts[(size_t)t]); });
+         const double w1 = now_s();
+         if (fo_regular) {
+            std::vector<int64_t> at((size_t)T + 1, fo_off);
+            for (int t = 0; t < T; t++) at[(size_t)t + 1] = at[(size_t)t] + (int64_t)parts[(size_t)t].size();
+            std::vector<int> bad((size_t)T, 0);
+            gm_parallel_for(T, [&](int t) {
+               const auto &part = parts[(size_t)t];
+               if (!part.empty() && write_all(fo, part.data(), part.size(), at[(size_t)t]) != 0) bad[(size_t)t] = 1;
+            });
+            for (int x : bad) if (x) writer_rc = -1;
+            fo_off = at[(size_t)T];
          } else {
-            rc = gpumap_batch_refill_text(ctx, b, j->chunk.text.data(), j->chunk.offsets.data(), j->n);
+            for (auto &part : parts)
+               if (!part.empty() && write_all(fo, part.data(), part.size(), -1) != 0) writer_rc = -1;
          }
-         const double g1 = now_s();
-         if (rc == 0) rc = gpumap_batch_run(ctx, b, tau, 0);
-         const double g2 = now_s();
-         // the arena this fetch writes to was handed out two fetches ago: its chunk is written once the
-         // writer has taken the chunk after it
-         if (rc == 0) to_writer.wait_empty();
-         const double g3 = now_s();
-         if (rc == 0) rc = gpumap_batch_fetch(ctx, b, &j->h);
-         t_upload += g1 - g0; t_run += g2 - g1; t_wait += g3 - g2; t_fetch += now_s() - g3;
-         if (rc != 0 || !to_writer.push(j)) { gpumap_hits_free(&j->h); delete j; failed = true; break; }
+         t_wait += w0 - w_1; t_format += w1 - w0; t_write += now_s() - w1;
+         gpumap_pipe_release(pipe, &j->h);
+         if (!spare.push(j)) delete j;
+         if (writer_rc != 0) break;
       }
-      to_gpu.close();
+      // on an error the reader may be waiting for a chunk object or for a slot: the results still in flight are
+      // taken and dropped until the pipe has been closed and has run empty
       spare.close();
+      if (failed || writer_rc != 0) {
+         gpumap_hits h;
+         void *user = nullptr;
+         int got;
+         while ((got = gpumap_pipe_next(pipe, &h, &user)) != 0) {
+            if (got > 0) gpumap_pipe_release(pipe, &h);
+            delete (Job *)user;
+         }
+      }
       reader.join();
-      to_gpu.drain();
-      to_writer.close();       // the writer finishes what it holds: pop() hands out queued jobs before nullptr
-      writer.join();
-      to_writer.drain();
       spare.drain();
       if (getenv("GPUMAP_MAPPER_VERBOSE"))
-         fprintf(stderr, "mapper stages (s): reader read %.3f parse %.3f | gpu upload %.3f run %.3f wait-for-writer %.3f fetch %.3f | "
-                 "writer format %.3f write %.3f | wall %.3f\n", t_read, t_parse, t_upload, t_run, t_wait, t_fetch, t_format, t_write,
-                 now_s() - t_begin);
+         fprintf(stderr, "mapper stages (s): reader read %.3f parse %.3f | writer wait-for-gpu %.3f format %.3f write %.3f | wall %.3f\n",
+                 t_read, t_parse, t_wait, t_format, t_write, now_s() - t_begin);
    }
    GM_FAIL_IF(failed, "batch failed.");
    GM_FAIL_IF(reader_rc != 0, "error while reading the read file.");
    GM_FAIL_IF(writer_rc != 0, "error while writing the output.");
-   gpumap_batch_free(b);
+   gpumap_pipe_destroy(pipe);
    if (fo_own) close(fo);
    gm_reads_close(in);
    return 0;
 failure_return:
-   gpumap_batch_free(b);
+   if (reader.joinable()) { spare.close(); if (pipe) gpumap_pipe_close(pipe); reader.join(); }
+   gpumap_pipe_destroy(pipe);
    if (fo_own && fo >= 0) close(fo);
    gm_reads_close(in);
    return -1;
+}
+
+extern "C" int gpumap_mapper(const char *qfile, const gpumap_index *index, gpumap_ctx *ctx, int tau, const char *out_path)
+{
+   return mapper_run(qfile, index, &ctx, 1, tau, out_path);
+}
+
+// mapper() over several GPUs: `ctxs` are replicas of one index (gpumap_multi_ctx); the chunks of the read file go
+// round the GPUs, the output is in input order, byte for byte what one GPU writes.
+extern "C" int gpumap_mapper_multi(const char *qfile, const gpumap_index *index, gpumap_ctx *const *ctxs, int n_ctx, int tau,
+                                   const char *out_path)
+{
+   return mapper_run(qfile, index, ctxs, n_ctx, tau, out_path);
 }

@@ -1,0 +1,177 @@
+// gm_pipe.cpp -- gpumap_pipe: the chunk loop of mapper() (src/mapper.c:23-40) as a pipeline over batch objects.
+// Every slot owns a batch (own HIP stream, scratch and page-locked result arena) and a worker thread that
+// takes a chunk through stage -> run (encode + search + locate + order) -> fetch.  Slots work side by side:
+// while one slot's kernels run, another's chunk is on its way to the device and a third's results are on
+// their way back, the three transfers being asynchronous copies and kernels on different streams.  Chunks go
+// round the slots, slots go round the contexts (GPUs), results come back in submit order.
+// Host code only: the device work is behind gm_batch_fill / gm_batch_run / gm_batch_fetch (gm_device.hip).
+#include <condition_variable>
+#include <cstring>
+#include <mutex>
+#include <thread>
+#include "gm_host.hpp"
+
+namespace {
+enum SlotState { SLOT_FREE, SLOT_QUEUED, SLOT_DONE, SLOT_RETURNED };
+struct Slot {
+   gpumap_ctx *ctx = nullptr;
+   gpumap_batch *batch = nullptr;
+   std::thread worker;
+   SlotState state = SLOT_FREE;
+   const void *src = nullptr;
+   const int64_t *offsets = nullptr;
+   int64_t n_reads = 0;
+   void *user = nullptr;
+   gpumap_hits hits;
+   int rc = 0;
+};
+}  // namespace
+
+struct gpumap_pipe {
+   std::vector<Slot> slots;
+   int tau = 0, src_flags = 0, result_flags = 0;
+   uint64_t submitted = 0, returned = 0;
+   bool closed = false, stop = false;
+   std::mutex m;
+   std::condition_variable cv;
+};
+
+static void pipe_worker(gpumap_pipe *p, Slot *s)
+{
+   for (;;) {
+      {
+         std::unique_lock<std::mutex> l(p->m);
+         p->cv.wait(l, [&] { return s->state == SLOT_QUEUED || p->stop; });
+         if (p->stop) return;
+      }
+      memset(&s->hits, 0, sizeof s->hits);
+      int rc = gm_batch_fill(s->ctx, s->batch, s->src, s->offsets, s->n_reads, p->src_flags, false);
+      if (rc == 0) rc = gm_batch_run(s->ctx, s->batch, p->tau, 0, p->result_flags);
+      if (rc == 0) rc = gm_batch_fetch(s->ctx, s->batch, &s->hits, p->result_flags);
+      {
+         std::lock_guard<std::mutex> l(p->m);
+         s->rc = rc;
+         s->state = SLOT_DONE;
+      }
+      p->cv.notify_all();
+   }
+}
+
+extern "C" void gpumap_pipe_destroy(gpumap_pipe *p)
+{
+   if (!p) return;
+   {
+      std::unique_lock<std::mutex> l(p->m);
+      // chunks in flight are finished first: their source buffers and the batch objects are in use
+      p->cv.wait(l, [&] { for (auto &s : p->slots) if (s.state == SLOT_QUEUED) return false; return true; });
+      p->stop = true;
+   }
+   p->cv.notify_all();
+   for (auto &s : p->slots) {
+      if (s.worker.joinable()) s.worker.join();
+      gpumap_batch_free(s.batch);
+   }
+   delete p;
+}
+
+extern "C" gpumap_pipe *gpumap_pipe_create(gpumap_ctx *const *ctxs, int n_ctx, int depth, int tau, int flags)
+{
+   gpumap_pipe *p = nullptr;
+   GM_FAIL_IF(ctxs == nullptr || n_ctx < 1, "no context.");
+   for (int i = 0; i < n_ctx; i++) GM_FAIL_IF(ctxs[i] == nullptr, "a context is NULL.");
+   GM_FAIL_IF(depth < 1 || depth > 16, "depth out of range (1..16).");
+   GM_FAIL_IF(tau < 0 || tau > GPUMAP_MAX_TAU, "argument 'tau' out of range.");
+   GM_FAIL_IF(flags & ~(GPUMAP_SRC_TEXT | GPUMAP_SRC_DEVICE | GPUMAP_PIPE_COMPACT), "unknown flag.");
+   GM_FAIL_IF((flags & GPUMAP_SRC_DEVICE) && n_ctx > 1, "device-resident chunks belong to one GPU: one context.");
+   p = new gpumap_pipe();
+   p->tau = tau;
+   p->src_flags = flags & (GPUMAP_SRC_TEXT | GPUMAP_SRC_DEVICE);
+   p->result_flags = GM_RESULT_PINNED | GM_RESULT_ONE_ARENA | ((flags & GPUMAP_PIPE_COMPACT) ? GM_RESULT_COMPACT : 0);
+   p->slots = std::vector<Slot>((size_t)depth * (size_t)n_ctx);
+   for (size_t i = 0; i < p->slots.size(); i++) {
+      Slot &s = p->slots[i];
+      s.ctx = ctxs[i % (size_t)n_ctx];                   // consecutive chunks go to different GPUs
+      s.batch = gpumap_batch_new(s.ctx);
+      GM_FAIL_IF(s.batch == nullptr, "cannot create a batch.");
+   }
+   for (auto &s : p->slots) s.worker = std::thread(pipe_worker, p, &s);
+   return p;
+failure_return:
+   gpumap_pipe_destroy(p);
+   return nullptr;
+}
+
+extern "C" int gpumap_pipe_submit(gpumap_pipe *p, const void *src, const int64_t *offsets, int64_t n_reads, void *user)
+{
+   GM_FAIL_IF(p == nullptr, "argument 'pipe' is NULL.");
+   GM_FAIL_IF(offsets == nullptr || n_reads < 0, "invalid arguments.");
+   {
+      std::unique_lock<std::mutex> l(p->m);
+      GM_FAIL_IF(p->closed, "the pipe is closed.");
+      Slot &s = p->slots[p->submitted % p->slots.size()];
+      p->cv.wait(l, [&] { return s.state == SLOT_FREE; });
+      s.src = src; s.offsets = offsets; s.n_reads = n_reads; s.user = user;
+      s.state = SLOT_QUEUED;
+      p->submitted++;
+   }
+   p->cv.notify_all();
+   return 0;
+failure_return:
+   return -1;
+}
+
+extern "C" int64_t gpumap_pipe_in_flight(gpumap_pipe *p)
+{
+   if (!p) return 0;
+   std::lock_guard<std::mutex> l(p->m);
+   return (int64_t)(p->submitted - p->returned);
+}
+
+extern "C" void gpumap_pipe_close(gpumap_pipe *p)
+{
+   if (!p) return;
+   { std::lock_guard<std::mutex> l(p->m); p->closed = true; }
+   p->cv.notify_all();
+}
+
+extern "C" int gpumap_pipe_next(gpumap_pipe *p, gpumap_hits *out, void **user)
+{
+   GM_FAIL_IF(p == nullptr || out == nullptr, "NULL argument.");
+   {
+      std::unique_lock<std::mutex> l(p->m);
+      // a caller with a thread of its own for the results waits here for the submitting thread; a single-threaded
+      // caller only asks when it has something in flight
+      p->cv.wait(l, [&] { return p->returned < p->submitted || p->closed; });
+      if (p->returned == p->submitted) return 0;
+      Slot &s = p->slots[p->returned % p->slots.size()];
+      p->cv.wait(l, [&] { return s.state == SLOT_DONE; });
+      p->returned++;
+      if (user) *user = s.user;
+      if (s.rc != 0) {
+         memset(out, 0, sizeof *out);
+         s.state = SLOT_FREE;
+         l.unlock();
+         p->cv.notify_all();
+         GM_FAIL("a chunk failed in the pipeline.");
+      }
+      *out = s.hits;
+      s.state = SLOT_RETURNED;
+   }
+   return 1;
+failure_return:
+   return -1;
+}
+
+extern "C" void gpumap_pipe_release(gpumap_pipe *p, gpumap_hits *hits)
+{
+   if (!p || !hits) return;
+   {
+      std::lock_guard<std::mutex> l(p->m);
+      for (auto &s : p->slots)
+         if (s.state == SLOT_RETURNED && s.hits.arena == hits->arena && s.hits.status == hits->status) { s.state = SLOT_FREE; break; }
+   }
+   const bool expanded = hits->expanded != 0;
+   if (expanded) gpumap_hits_free(hits);            // (frees what gpumap_hits_expand added; the arena is the pipe's)
+   else memset(hits, 0, sizeof *hits);
+   p->cv.notify_all();
+}

@@ -154,6 +154,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_search(SearchArgs A)
    wq.q = s_q[wid];
    wq.spill = A.spill + (size_t)gw * A.spill_cap;
    wq.bot = wq.top = wq.spill_top = 0;
+   wq.n_spilled = 0;
    wq.spill_cap = A.spill_cap;
    wq.error = A.error;
    uint4 *stage = s_stage[wid];
@@ -223,8 +224,8 @@ __global__ void __launch_bounds__(WG_THREADS) k_search(SearchArgs A)
                   if (mk) {
                      uint32_t rd = (uint32_t)(base + r);
                      int m = A.read_len[rd];
-                     int row = m <= MAX_READ ? A.len_row[m] : 0xff;
-                     mk = row != 0xff;
+                     int row = m <= MAX_READ ? A.len_row[m] : NO_ROW;
+                     mk = row != NO_ROW;
                      if (mk) {
                         NodeR sd;
                         sd.fp = 0; sd.rp = 0; sd.sz = A.ix.n;        // bwt_new_query, src/index_bwt.c:48-52
@@ -399,6 +400,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_search(SearchArgs A)
       }
    }
    hit_finish(A, hr, lane);
+   if (lane == 0 && wq.n_spilled) atomicAdd(A.stats + 4, (unsigned long long)wq.n_spilled);
    for (int o = 32; o > 0; o >>= 1) jump_steps += (uint32_t)__shfl_xor((int)jump_steps, o);
    ext_count += jump_steps;
    if (lane == 0 && ext_count) {

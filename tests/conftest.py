@@ -3,6 +3,13 @@ import sys
 
 import pytest
 
+# torch (used by some GPU tests to generate data in HBM) brings its own copy of the HIP runtime: it has to be
+# loaded before libgpumap.so pulls in /opt/rocm's, or torch finds no GPU later in the same process.
+try:
+    import torch  # noqa: F401
+except ImportError:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
