@@ -10,8 +10,11 @@ repacks it on its GPU and broadcasts the three device arrays once over xGMI with
 replica.  No collective on the data path: reads are independent units (weak scaling: the per-GPU
 batch is fixed, value = reads of all ranks / max-over-ranks time).
 
-A "step" is one pass of the hot path over one batch of reads already resident in HBM:
-gpumap_batch_run = search (k_search) + suffix-array locate + ordering, results left on the device.
+A "step" is one pass of the hot path over one chunk of reads whose letters are resident in HBM when the
+timed region starts: encode (k_encode, k_pack_planes) + search (k_search, k_verify) +
+suffix-array locate + ordering + the copy of the hits to page-locked host memory (compact results: sorted
+8-byte keys + CSR offsets).  Steps cycle over 8 distinct chunks and go through the library's pipeline
+(gpumap_pipe), so that the copy of one chunk's hits overlaps the next chunk's kernels.
 Default workload: the GRCh38-size index of config 4 (synthetic, generated and indexed in HBM).
 
 One JSON line is printed by rank 0; see DESIGN.md section "Measurement" for the accounting of
@@ -67,6 +70,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=os.environ.get("GPUMAP_WORKLOAD", "grch38"))
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU (0 = the workload's)")
+    ap.add_argument("--chunks", type=int, default=8, help="distinct chunks of reads per GPU resident in HBM")
+    ap.add_argument("--depth", type=int, default=3, help="batch objects of the pipeline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--waves-per-cu", type=int, default=0)
@@ -171,16 +176,35 @@ def main():
     if args.verify >= 0:
         ctx.set_option("verify", args.verify)
 
-    # this rank's shard: its own reads (weak scaling), resident in HBM before the timed region
-    if on_device:
-        rd = synth_device.make_reads(g, lens, w["reads"], w["m"], w["tau"], seed=read_seed)
-        codes = rd.cpu().numpy()
-        offs = np.arange(w["reads"] + 1, dtype=np.int64) * w["m"]
-        del rd, g
-        torch.cuda.empty_cache()
-    else:
-        codes, offs = synth.make_reads(seqs, w["reads"], w["m"], w["tau"], seed=read_seed)
-    batch = ctx.upload(codes.reshape(-1), offs)
+    # this rank's shard: its own reads (weak scaling).  n_chunks distinct chunks of reads_per_gpu reads each, their
+    # LETTERS and offsets resident in HBM before the timed region starts (8 x 12.5 M = the 100 M reads of config 4
+    # on one GPU); the first chunk also on the host (CPU baseline, parity sample, PCIe-inclusive figures)
+    ascii_lut = torch.tensor(list(b"ACGTN"), dtype=torch.uint8, device="cuda")
+
+    def to_letters(rd):
+        flat = rd.reshape(-1)
+        out = torch.empty_like(flat)
+        for lo in range(0, flat.numel(), 1 << 27):
+            out[lo:lo + (1 << 27)] = ascii_lut[flat[lo:lo + (1 << 27)].long()]
+        return out
+
+    if not on_device:
+        from mapper_amd import synth_device
+        g = torch.from_numpy(np.concatenate(seqs)).cuda()
+        lens = np.array([len(x) for x in seqs], dtype=np.int64)
+    d_offs = (torch.arange(w["reads"] + 1, dtype=torch.int64, device="cuda") * w["m"]).contiguous()
+    d_chunks = []
+    codes = None
+    for k in range(args.chunks):
+        rd = synth_device.make_reads(g, lens, w["reads"], w["m"], w["tau"], seed=read_seed + 7919 * k)
+        if k == 0:
+            codes = rd.cpu().numpy()
+        d_chunks.append(to_letters(rd))
+        del rd
+    offs = np.arange(w["reads"] + 1, dtype=np.int64) * w["m"]
+    del g
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
     t_setup = time.time() - t_setup
     note("reads resident, timing")
 
@@ -190,68 +214,162 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        batch.run(w["tau"])
+    # ---- the timed region: encode + search + locate + order + D2H of the hits, chunk after chunk through
+    # the library's pipeline (gpumap_pipe: `depth` batch objects with streams of their own, so that the copy of one
+    # chunk's results overlaps the next chunk's kernels); inputs = letters in HBM, outputs = compact results
+    # (sorted 8-byte keys + CSR offsets + status) in page-locked host memory.
+    lib = ma.lib()
+    pipe = ctx.pipe(depth=args.depth, tau=w["tau"], flags=ma.SRC_TEXT | ma.SRC_DEVICE | ma.PIPE_COMPACT)
+    n_reads = w["reads"]
+
+    def run_steps(k_steps, first=0):
+        located = 0
+        taken = 0
+        for k in range(k_steps):
+            if k - taken == args.depth:
+                raw, _ = pipe.next_raw()
+                located += int(raw.n_locs)
+                pipe.release_raw(raw)
+                taken += 1
+            pipe.submit(d_chunks[(first + k) % len(d_chunks)].data_ptr(), d_offs.data_ptr(), n_reads)
+        while taken < k_steps:
+            raw, _ = pipe.next_raw()
+            located += int(raw.n_locs)
+            pipe.release_raw(raw)
+            taken += 1
+        return located
+
+    run_steps(args.depth)                       # every slot allocates its device buffers and its result arena (set-up)
+    run_steps(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    ms_search, ms_k_search, ms_k_verify = [], [], []
-    for _ in range(args.steps):
-        c = batch.run(w["tau"])                      # synchronous: returns when the device work is done
-        ms_search.append(c["ms_search"])
-        ms_k_search.append(c["us_k_search"] / 1000.0)
-        ms_k_verify.append(c["us_k_verify"] / 1000.0)
+    located_total = run_steps(args.steps, first=args.warmup)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    c = batch.counters()
+
+    # ---- the same work one chunk at a time on one batch object, for the per-kernel times (in the pipeline the
+    # kernels of different chunks overlap, so their event times are not per-kernel times)
+    batch = ctx.new_batch()
+    ctx.set_option("compact_results", 1)
+    per = {k: [] for k in ("encode", "k_search", "k_verify", "locate", "order", "device_total")}
+    for i in range(max(2, min(args.steps, 4)) + 1):
+        batch.stage(d_chunks[i % len(d_chunks)].data_ptr(), (d_offs.data_ptr(), n_reads), ma.SRC_TEXT | ma.SRC_DEVICE)
+        t1 = time.perf_counter()
+        c = batch.run(w["tau"])
+        dt = time.perf_counter() - t1
+        if i == 0:
+            continue                            # (allocations)
+        e = batch.stats_ext()
+        per["encode"].append(e["us_encode"] / 1000.0)
+        per["k_search"].append(c["us_k_search"] / 1000.0)
+        per["k_verify"].append(c["us_k_verify"] / 1000.0)
+        per["locate"].append(c["ms_locate"])
+        per["order"].append(c["ms_sort"])
+        per["device_total"].append(1e3 * dt)
+    e = batch.stats_ext()
+    ctx.set_option("compact_results", 0)
+    # replicas: every rank maps the same small sample; the checksums of the sorted keys must agree
+    replica = None
+    if world > 1:
+        ns = min(20000, n_reads)
+        h = ctx.map_batch(codes[:ns].reshape(-1), offs[:ns + 1], w["tau"])
+        mine = np.array([int(h.n_locs), int(np.bitwise_xor.reduce(h.located().reshape(-1) * np.int64(0x9E3779B97F4A7C15 >> 1))) if h.n_locs else 0],
+                        dtype=np.int64)
+        allv = [torch.zeros(2, dtype=torch.int64, device="cuda") for _ in range(world)]
+        dist.all_gather(allv, torch.from_numpy(mine).cuda())
+        allv = [tuple(v.cpu().tolist()) for v in allv]
+        replica = {"sample_reads": ns, "located": int(mine[0]), "identical_across_ranks": len(set(allv)) == 1}
 
     if rank == 0:
-        total_reads = w["reads"] * world * args.steps
+        total_reads = n_reads * world * args.steps
         value = total_reads / elapsed
+        mean = {k: float(np.mean(v)) for k, v in per.items()}
         # dominant kernel: k_search.  Its units are the extension steps it executes on the Occ table (the rest of
         # the reference schedule's steps are served by the jump table and replayed on the text by k_verify).
-        k_ms = float(np.mean(ms_k_search))
+        k_ms = mean["k_search"]
         occ_steps = c["n_ext"] - c["jumped_steps"] - c["verify_steps"]
         achieved = BYTES_PER_EXT * occ_steps / (k_ms * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic(args.workload)
-        search_ms = float(np.mean(ms_search))
+        traffic, traffic_src, requests = pmc_traffic(args.workload)
+        gather = gather_ceiling(2 * (w["L"] + w["n_seqs"]) // 2)     # Occ blocks: half a byte per text position
+        if gather:
+            gather["algorithmic_Glines_per_s"] = 2.0 * occ_steps / (k_ms * 1e-3) / 1e9
+            gather["frac_algorithmic"] = gather["algorithmic_Glines_per_s"] / gather["ceiling_Glines_per_s"]
+            if requests:
+                gather["hbm_requests_per_launch"] = requests
+                gather["hbm_requests_Glines_per_s"] = requests / (k_ms * 1e-3) / 1e9
+                gather["frac_of_gather"] = gather["hbm_requests_Glines_per_s"] / gather["ceiling_Glines_per_s"]
+                gather["note"] = ("frac_of_gather = HBM read requests of k_search (committed PMC pass) / live kernel time / live ceiling; "
+                                  "frac_algorithmic counts 2 lines per step and exceeds it where the two ranks of a step share a line")
+        H, L, W = c["list_length"], c["n_locs"], e["verify_windows"]
+
+        def kern(name, ms, units, unit, bytes_per_unit, note_):
+            by = float(bytes_per_unit) * units
+            return {"kernel": name, "ms": ms, "unit": unit, "units_per_launch": units, "algorithmic_bytes": by,
+                    "achieved_GBps": by / (ms * 1e-3) / 1e9 if ms > 0 else None,
+                    "frac_hbm": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else None, "accounting": note_}
+        kernels = [
+            kern("k_search", k_ms, occ_steps, "extension step on the Occ table", 128, "two 64-B Occ lines per step (SURVEY 8d)"),
+            kern("k_verify", mean["k_verify"], W, "suffix replayed on the text", 232,
+                 "64 B suffix-array line + 64 B text window + 48 B query planes + 32 B list entry + 24 B key and slot count"),
+            kern("scan + k_place + k_place_long", mean["locate"], H, "list entry", 24.0 + 8.0 * L / max(H, 1),
+                 "24 B per list entry + 8 B per located position (suffix-array lines of intervals not counted)"),
+            kern("radix sort + k_read_first", mean["order"], L, "located position", 24,
+                 "8-B key read and written once + CSR offset; the sort makes 8 passes over the keys"),
+            kern("k_encode + k_pack_planes", mean["encode"], n_reads * w["m"], "letter", 2.375,
+                 "1 B letter in, 1 B code out, 3 bits of planes"),
+        ]
         out = {
-            "metric": "reads mapped/sec (node), 100nt <=2 mm; % HBM gather roofline",
+            "metric": "reads mapped/sec (node), GRCh38-size index, %dnt <=%d mm; %% HBM gather roofline" % (w["m"], w["tau"])
+                      if args.workload.startswith("grch38") else
+                      "reads mapped/sec (node), %s index, %dnt <=%d mm; %% HBM gather roofline" % (args.workload, w["m"], w["tau"]),
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int64", "data": "synthetic",
             "config": {"workload": args.workload, "description": w["desc"], "text_len": int(2 * (w["L"] + w["n_seqs"])),
-                       "reads_per_gpu": w["reads"], "read_len": w["m"], "tau": w["tau"],
+                       "reads_per_gpu_per_step": n_reads, "distinct_chunks_per_gpu": len(d_chunks), "read_len": w["m"], "tau": w["tau"],
+                       "timed_region": "per step one chunk: letters resident in HBM -> encode + search + locate + order + D2H of "
+                                       "compact results (8-B keys + CSR offsets + status) into page-locked host memory; "
+                                       "chunks pipelined over %d batch objects (gpumap_pipe)" % args.depth,
                        "parallelism": "reads sharded over %d GPU(s), index replicated (RCCL broadcast)" % world},
+            "located_per_step": located_total / args.steps,
+            "device_resident": {"reads_per_s": n_reads / (mean["device_total"] * 1e-3), "ms_per_chunk": mean["device_total"],
+                                "note": "one chunk at a time on one batch object, results left in HBM (no D2H, no overlap): "
+                                        "encode + search + locate + order; round 1's headline was this without the encoding"},
             "roofline": {"bound": "hbm", "kernel": "k_search", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel_ms": k_ms, "ext_steps_per_launch": occ_steps,
                          "algorithmic_bytes_per_launch": BYTES_PER_EXT * occ_steps,
-                         "k_verify_ms": float(np.mean(ms_k_verify)),
+                         "k_verify_ms": mean["k_verify"],
+                         "gather": gather,
+                         "kernels": kernels,
                          "reference_schedule": {"ext_steps": c["n_ext"], "bytes": BYTES_PER_EXT * c["n_ext"],
-                                                "retired_GBps": BYTES_PER_EXT * c["n_ext"] / (search_ms * 1e-3) / 1e9,
+                                                "retired_GBps": BYTES_PER_EXT * c["n_ext"] / ((k_ms + mean["k_verify"]) * 1e-3) / 1e9,
                                                 "note": "SURVEY 8d bytes of the whole reference schedule over k_search + k_verify "
                                                         "time: a rate of work retired, not a traffic (can exceed the HBM peak)"}},
-            "stages_ms": {"search": c["ms_search"], "locate": c["ms_locate"], "order": c["ms_sort"],
-                          "total": c["ms_total"]},
-            "hits_per_batch": {"list_entries": c["n_hits"], "list_length": c["list_length"], "located": c["n_locs"]},
+            "stages_ms": {"encode": mean["encode"], "search": mean["k_search"] + mean["k_verify"], "locate": mean["locate"],
+                          "order": mean["order"], "chunk_on_device": mean["device_total"]},
+            "hits_per_batch": {"list_entries": c["n_hits"], "list_length": c["list_length"], "located": c["n_locs"],
+                               "verify_windows": W},
             "occupancy": {"loop_passes": c["loop_passes"], "continuations": c["continuations"],
                           "steps_from_jump_table": c["jumped_steps"], "steps_replayed_on_text": c["verify_steps"],
-                          "steps_on_occ_table": c["n_ext"] - c["jumped_steps"] - c["verify_steps"],
-                          "lane_fill": ((c["n_ext"] - c["jumped_steps"] - c["verify_steps"]) / (64.0 * c["loop_passes"]))
-                          if c["loop_passes"] else None},
+                          "steps_on_occ_table": occ_steps,
+                          "lane_fill": (occ_steps / (64.0 * c["loop_passes"])) if c["loop_passes"] else None},
             "setup_s": {"index_build": t_index, "index_built_on": "device" if on_device else "host", "upload_repack": t_upload, "rccl_broadcast": t_bcast,
                         "all": t_setup},
         }
+        if replica:
+            out["replica_check"] = replica
         if world == 1:
-            out["pcie_inclusive"] = pcie_inclusive(ma, ctx, codes, offs, w)
+            out["pcie_inclusive"] = pcie_inclusive(ma, ctx, codes, offs, w, args.depth)
         if want_cpu:
             out["cpu_baseline"] = cpu_baseline(ctx if on_device else None, base, codes, offs, w, args.cpu_seconds, gpu_ctx=ctx)
         print(json.dumps(out), flush=True)
     batch.close()
+    pipe.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -259,16 +377,61 @@ def main():
     del keep
 
 
-def pcie_inclusive(ma, ctx, codes, offs, w):
-    """The boundary hands over host buffers: untimed-region figure for DESIGN.md, never `value`.  One pass of
-    upload (H2D of the reads) + search + locate + order + fetch (D2H of every located hit) per buffer kind:
-    pageable (malloc'ed results, any caller) and page-locked (gpumap_host_alloc + option pinned_results)."""
+def gather_ceiling(footprint_bytes):
+    """The measured ceiling north_star asks for: dependent random 64-B line reads over a footprint of the Occ
+    table's size, in the shape k_search uses (a quad of lanes per line), 32 waves per CU
+    (tools/gather_bench.hip, run as a child process on the same GPU)."""
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "_build", "gather_bench")
+    if not os.path.exists(exe):
+        return None
+    mib = max(16, int(footprint_bytes) >> 20)
+    try:
+        r = subprocess.run([exe, "quick", str(mib), "32", "2000"], capture_output=True, text=True, timeout=120)
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        return {"ceiling_Glines_per_s": d["Gtouch_per_s"], "footprint_MiB": d["footprint_MiB"], "shape": d["shape"],
+                "waves_per_cu": d["waves_per_cu"], "source": "tools/gather_bench.hip quick, this run"}
+    except Exception as ex:
+        return {"error": str(ex)}
+
+
+def pcie_inclusive(ma, ctx, codes, offs, w, depth):
+    """The boundary hands over host buffers: figures for DESIGN.md, never `value`.  (a) pipelined: chunks of letters
+    in page-locked host memory through gpumap_pipe (H2D + encode + search + locate + order + D2H of compact results,
+    the stages of consecutive chunks overlapping); (b) one shot: gpumap_map_batch, codes in, the full structure of
+    arrays out, pageable (malloc'ed results, any caller) and page-locked (gpumap_host_alloc + option pinned_results)."""
     import ctypes as C
     lib = ma.lib()
     flat = np.ascontiguousarray(codes.reshape(-1))
+    n = len(offs) - 1
     res = {}
-    pin = lib.gpumap_host_alloc(flat.nbytes)
-    pflat = np.ctypeslib.as_array(C.cast(pin, C.POINTER(C.c_uint8)), shape=(flat.nbytes,))
+    lut = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    pins = []
+    for k in range(2):
+        pin = lib.gpumap_host_alloc(flat.nbytes)
+        v = np.ctypeslib.as_array(C.cast(pin, C.POINTER(C.c_uint8)), shape=(flat.nbytes,))
+        v[:] = lut[np.roll(flat, 1000 * k * w["m"])]                   # (the same reads in another order)
+        pins.append((pin, v))
+    pipe = ctx.pipe(depth=depth, tau=w["tau"], flags=ma.SRC_TEXT | ma.PIPE_COMPACT)
+    off_arr = np.ascontiguousarray(offs, dtype=np.int64)
+
+    def go(k_steps):
+        taken = 0
+        for k in range(k_steps):
+            if k - taken == depth:
+                raw, _ = pipe.next_raw(); pipe.release_raw(raw); taken += 1
+            if lib.gpumap_pipe_submit(pipe._h, C.c_void_p(pins[k % 2][0]), off_arr.ctypes.data_as(C.c_void_p), n, None) != 0:
+                raise RuntimeError("gpumap_pipe_submit failed")
+        while taken < k_steps:
+            raw, _ = pipe.next_raw(); pipe.release_raw(raw); taken += 1
+    go(depth)
+    t0 = time.perf_counter()
+    go(6)
+    dt = (time.perf_counter() - t0) / 6
+    pipe.close()
+    res["pipelined_pinned"] = {"reads_per_s": n / dt, "seconds_per_chunk": dt, "chunks": 6,
+                               "what": "letters in page-locked host memory -> H2D + encode + search + locate + order + D2H (compact), gpumap_pipe"}
+    pflat = pins[0][1]
     pflat[:] = flat
     for mode, src in (("pageable", flat), ("pinned", pflat)):
         ctx.set_option("pinned_results", 1 if mode == "pinned" else 0)
@@ -283,49 +446,74 @@ def pcie_inclusive(ma, ctx, codes, offs, w):
             nl = int(raw.n_locs)
             lib.gpumap_hits_free(C.byref(raw))
             best = dt if best is None else min(best, dt)
-        res[mode] = {"reads_per_s": (len(offs) - 1) / best, "seconds": best, "located": nl}
+        res[mode] = {"reads_per_s": (len(offs) - 1) / best, "seconds": best, "located": nl,
+                     "what": "gpumap_map_batch: one shot, full structure of arrays"}
     ctx.set_option("pinned_results", 0)
-    lib.gpumap_host_free(pin)
+    for pin, _ in pins:
+        lib.gpumap_host_free(pin)
     return res
 
 
 def pmc_traffic(workload):
-    """HBM-side bytes per launch of the search kernel from the committed rocprofv3 PMC passes of this same
-    command (tools/profile_passes.sh -> profiles/r1_<workload>_profile_summary.json): (FETCH_SIZE +
+    """HBM-side bytes and read requests per launch of the search kernel from the committed rocprofv3 PMC passes of
+    this same command (tools/profile_passes.sh -> profiles/r<round>_<workload>_profile_summary.json): (FETCH_SIZE +
     WRITE_SIZE) * 1024.  FETCH_SIZE = TCC_EA0_RDREQ * 64 B here (every request of this kernel is one
     64-byte line, TCC_EA0_RDREQ_32B = 0), so the factor 2 of wide coalesced streams does not apply
     (MI355X_MICROARCH.md, HBM).  None when no profile of this workload is committed."""
-    path = os.path.join(ROOT, "profiles", "r1_%s_profile_summary.json" % workload)
-    try:
-        pm = json.load(open(path))["pmc_per_launch"]
-        k = pm.get("gm::k_search") or pm.get("gm::k_search_lane") or next(iter(pm.values()))
-        return (k["FETCH_SIZE"]["avg"] + k["WRITE_SIZE"]["avg"]) * 1024.0, os.path.relpath(path, ROOT)
-    except Exception:
-        return None, None
+    for rnd in ("r2", "r1"):
+        path = os.path.join(ROOT, "profiles", "%s_%s_profile_summary.json" % (rnd, workload))
+        try:
+            pm = json.load(open(path))["pmc_per_launch"]
+            k = pm.get("gm::k_search") or next(iter(pm.values()))
+            req = k.get("TCC_EA0_RDREQ_sum", {}).get("avg")
+            return (k["FETCH_SIZE"]["avg"] + k["WRITE_SIZE"]["avg"]) * 1024.0, os.path.relpath(path, ROOT), req
+        except Exception:
+            continue
+    return None, None, None
 
 
 def cpu_baseline(ctx, base, codes, offs, w, seconds, gpu_ctx=None):
     """The oracle's C restatement (kind "port") on the host cores, on a bounded sample of the same
     reads against the same index (the files the host builder wrote, or the reference-layout arrays of
-    a device build copied back).  Test infrastructure used as the baseline only."""
+    a device build copied back).  Test infrastructure used as the baseline only.  Three thread counts: 1, the CPUs
+    this job may run on (its affinity mask / the box's share), and nproc (every CPU the machine shows)."""
     from oracle import pyoracle as po
     if ctx is None:
         orc = po.Index(base)
     else:
         ref = ctx.reference_arrays(want_text=False)
         orc = po.Index.from_arrays(ref["occ"], ref["c"], ref["sa"], ref["sar_bits"], ref["txt_len"], ref["wil_cnt"])
-    cores = min(16, os.cpu_count() or 1)
-    probe = min(len(offs) - 1, 4000 * cores)
-    d = orc.map_batch(codes[:probe].reshape(-1), offs[:probe + 1], w["tau"], threads=cores)
-    rate = probe / max(d.seconds, 1e-6)
-    n = int(min(len(offs) - 1, max(probe, rate * seconds)))
-    d = orc.map_batch(codes[:n].reshape(-1), offs[:n + 1], w["tau"], threads=cores)
-    out = {"value": n / d.seconds, "unit": "reads/s", "cores": cores, "kind": "port",
-           "sample": "first %d reads of the batch, %d pthreads, %.1f s" % (n, cores, d.seconds),
-           "ext_steps_per_read": d.n_ext / n}
+    nproc = os.cpu_count() or 1
+    try:
+        share = len(os.sched_getaffinity(0))
+    except Exception:
+        share = nproc
+    if os.environ.get("OMP_NUM_THREADS", "").isdigit():
+        share = min(share, int(os.environ["OMP_NUM_THREADS"]))          # the box's CPU share per GPU job
+    runs = {}
+    best_t, best_d, best_n = None, None, 0
+    for T in sorted(set([1, share, min(nproc, 512)])):
+        probe = min(len(offs) - 1, 2000 * min(T, 64))
+        d = orc.map_batch(codes[:probe].reshape(-1), offs[:probe + 1], w["tau"], threads=T)
+        rate = probe / max(d.seconds, 1e-6)
+        n = int(min(len(offs) - 1, max(probe, rate * seconds / 2)))
+        d = orc.map_batch(codes[:n].reshape(-1), offs[:n + 1], w["tau"], threads=T)
+        runs["T=%d" % T] = {"reads_per_s": n / d.seconds, "threads": T, "reads": n, "seconds": d.seconds}
+        if best_d is None or n / d.seconds > best_n / best_d.seconds:
+            best_t, best_d, best_n = T, d, n
+    d, n = best_d, best_n
+    out = {"value": n / d.seconds, "unit": "reads/s", "cores": best_t, "kind": "port", "nproc": nproc, "cpu_share": share,
+           "sample": "first %d reads of the first chunk, %d pthreads, %.1f s (the fastest of the thread counts tried)" % (n, best_t, d.seconds),
+           "by_threads": runs, "ext_steps_per_read": d.n_ext / n}
     if gpu_ctx is not None:
-        # the same sample through the HIP path: mapped positions, strands (position >= n/2) and scores must be identical
-        h = gpu_ctx.map_batch(codes[:n].reshape(-1), offs[:n + 1], w["tau"])
+        # the same sample through the HIP path (compact results, as in the timed region): status, mapped positions,
+        # strands (position >= n/2), scores and the count of extension steps must be identical
+        gpu_ctx.set_option("compact_results", 1)
+        b = gpu_ctx.upload(codes[:n].reshape(-1), offs[:n + 1])
+        b.run(w["tau"])
+        h = b.fetch()
+        b.close()
+        gpu_ctx.set_option("compact_results", 0)
         out["parity_on_sample"] = {"reads": n, "located": int(h.n_locs),
                                    "identical": bool(np.array_equal(h.status, d.status) and
                                                      np.array_equal(h.located(), d.located()) and h.n_ext == d.n_ext)}

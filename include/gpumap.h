@@ -265,7 +265,8 @@ int           gpumap_batch_stats(const gpumap_batch *batch, int64_t stats[8]);
 /* More of the same: stats[0] = searches the run took (2: the first guess of the hit list's length was too short and
 ** the search ran again with the exact length), stats[1] = microseconds of the encoding stage of a staged batch,
 ** stats[2] = 1 when the run left compact results, stats[3] = capacity of the hit list in entries, stats[4] = chunks
-** of 64 nodes that the wavefronts' deques spilled to global memory; the rest is 0. */
+** of 64 nodes that the wavefronts' deques spilled to global memory, stats[5] = suffixes (windows of the text)
+** that k_verify replayed; the rest is 0. */
 int           gpumap_batch_stats_ext(const gpumap_batch *batch, int64_t stats[8]);
 void          gpumap_batch_free(gpumap_batch *batch);
 

@@ -289,7 +289,8 @@ class Batch:
         st = (_I64 * 8)()
         if lib().gpumap_batch_stats_ext(self._h, st) != 0:
             raise GpumapError("gpumap_batch_stats_ext failed")
-        return dict(attempts=st[0], us_encode=st[1], compact=st[2], hit_list_capacity=st[3], spill_chunks=st[4])
+        return dict(attempts=st[0], us_encode=st[1], compact=st[2], hit_list_capacity=st[3], spill_chunks=st[4],
+                    verify_windows=st[5])
 
     def close(self):
         if self._h:

@@ -93,6 +93,7 @@ struct gpumap_ctx {
    int64_t hit_guess = 0;             // "hit_list_guess": first guess of the hit list's length in entries (0 = by the batch; tests)
    int64_t jump_budget = 0;           // "jump_bytes": most bytes the jump table may take (0 = a third of the free memory)
    std::vector<int64_t> seq_beg_host; // seq_beg[] (for gpumap_hits_expand)
+   hipStream_t pipe_run = nullptr, pipe_copy = nullptr, pipe_up = nullptr;   // streams shared by the batches of pipelines (gm_ctx_pipe_streams)
    gpumap_batch *map_batch_obj = nullptr;   // gpumap_map_batch with "pinned_results": the batch whose arenas hold the results
 };
 

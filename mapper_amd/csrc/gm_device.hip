@@ -20,7 +20,14 @@ using namespace gm;
 // context is only read while batches run.
 struct gpumap_batch {
    gpumap_ctx *ctx = nullptr;
-   hipStream_t stream = nullptr;
+   // Three streams: uploads (copies of the chunk to the device, k_read_lengths), the run's kernels, the copy of
+   // the results to the host.  A batch on its own uses its one stream for all three.  The batches of a pipeline
+   // share their context's three streams (gm_batch_set_streams): the kernels of consecutive chunks then run
+   // back to back on one stream (two persistent k_search launches side by side only slow each other down) while
+   // the result copy of the chunk before and the upload of the chunk after run on the other two.  That is why
+   // nothing below waits for a whole stream: every wait is for an event this batch recorded.
+   hipStream_t stream = nullptr, st_run = nullptr, st_copy = nullptr, st_up = nullptr;
+   hipEvent_t ev_sync = nullptr, ev_up = nullptr;
    int64_t n_reads = 0;
    int stride = 0, maxlen = 1;
    // the letters (or codes) of the reads in device memory: the library's copy of a host buffer (up_src, up_off;
@@ -42,6 +49,7 @@ struct gpumap_batch {
    bool length_seen[MAX_READ + 1];
    int64_t n_hits = 0, n_real = 0, n_locs = 0, n_ext = 0;
    int64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+   int64_t verify_windows = 0;       // suffixes k_verify replayed on the text in the last run
    int64_t spill_chunks = 0;         // chunks of SPILL_CHUNK nodes the deques of the last search moved to global memory
    int attempts = 0;                 // searches the last run took (2: the first guess of the hit list was too short)
    bool have_intervals = false, ran = false;
@@ -61,7 +69,7 @@ struct gpumap_batch {
                         &hit_dp, &hit_score, &hit_align, &spill, &counters, &cub_tmp})
          b->release();
       for (auto &e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
-      if (ev_seen) { (void)hipEventDestroy(ev_seen); ev_seen = nullptr; }
+      for (hipEvent_t *e : {&ev_seen, &ev_sync, &ev_up}) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
       for (void *&a : pin_arena) if (a) { (void)hipHostFree(a); a = nullptr; }
       pin_cap[0] = pin_cap[1] = 0;
       if (h_small) { (void)hipHostFree(h_small); h_small = nullptr; }
@@ -128,6 +136,7 @@ extern "C" void gpumap_destroy(gpumap_ctx *ctx)
    (void)hipSetDevice(ctx->device);
    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
    if (ctx->map_batch_obj) { gpumap_batch_free(ctx->map_batch_obj); ctx->map_batch_obj = nullptr; }
+   for (hipStream_t *st : {&ctx->pipe_run, &ctx->pipe_copy, &ctx->pipe_up}) if (*st) { (void)hipStreamSynchronize(*st); (void)hipStreamDestroy(*st); *st = nullptr; }
    if (ctx->owns_index) {
       if (ctx->d_occ) (void)hipFree(ctx->d_occ);
       if (ctx->d_tables) (void)hipFree(ctx->d_tables);
@@ -527,7 +536,7 @@ extern "C" void gpumap_batch_free(gpumap_batch *b)
 {
    if (!b) return;
    if (b->ctx) (void)hipSetDevice(b->ctx->device);
-   if (b->stream) (void)hipStreamSynchronize(b->stream);
+   for (hipStream_t st : {b->st_up, b->st_run, b->st_copy}) if (st) (void)hipStreamSynchronize(st);
    b->release();
    delete b;
 }
@@ -541,6 +550,9 @@ extern "C" gpumap_batch *gpumap_batch_new(gpumap_ctx *ctx)
    b->ctx = ctx;
    memset(b->length_seen, 0, sizeof b->length_seen);
    HIP_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+   b->st_run = b->st_copy = b->st_up = b->stream;
+   HIP_TRY(hipEventCreateWithFlags(&b->ev_sync, hipEventDisableTiming | hipEventBlockingSync));
+   HIP_TRY(hipEventCreateWithFlags(&b->ev_up, hipEventDisableTiming));
    HIP_TRY(hipHostMalloc((void **)&b->h_small, H_SMALL_BYTES, hipHostMallocDefault));
    HIP_TRY(hipEventCreateWithFlags(&b->ev_seen, hipEventDisableTiming));
    for (auto &e : b->ev) HIP_TRY(hipEventCreate(&e));
@@ -552,14 +564,54 @@ failure_return:
    return nullptr;
 }
 
+// The three streams the batches of a pipeline on this context share, created at the first call.  Streams of
+// different priority come from different pools of hardware queues in the HIP runtime: the copy stream (high
+// priority: on this platform copies are kernels, which take few wavefronts and should not queue behind persistent
+// search kernels) therefore never shares a hardware queue with the run stream, whatever other streams the
+// process has made (streams of one priority beyond GPU_MAX_HW_QUEUES share queues, and work on one queue is serial).
+int gm_ctx_pipe_streams(gpumap_ctx *ctx, void **run, void **copy, void **up)
+{
+   HIP_TRY(hipSetDevice(ctx->device));
+   {
+      std::lock_guard<std::mutex> lock(g_scratch_mutex);
+      if (ctx->pipe_run == nullptr) {
+         int least = 0, greatest = 0;
+         HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));      // numerically: greatest <= 0 <= least
+         // (a LOW-priority upload stream deadlocked: the run stream's wait for the upload's event kept the
+         // low-priority queue from being scheduled once several contexts shared the device.  Nothing waits on the
+         // device for a stream of lower priority now.)
+         // Measured at GRCh38 size, 12.5 M reads per chunk, chunks resident in HBM: copy stream high, upload stream
+         // normal 20.6 ms per chunk (19.5 without any copy); both high 22.0; from page-locked host memory 46 / 51 ms.
+         const int mode = getenv("GPUMAP_PIPE_PRIO") ? atoi(getenv("GPUMAP_PIPE_PRIO")) : 1;      // tuning aid: 0 = no priorities, 2 = upload high too
+         (void)least;
+         HIP_TRY(hipStreamCreateWithFlags(&ctx->pipe_run, hipStreamNonBlocking));
+         HIP_TRY(hipStreamCreateWithPriority(&ctx->pipe_copy, hipStreamNonBlocking, mode >= 1 ? greatest : 0));
+         HIP_TRY(hipStreamCreateWithPriority(&ctx->pipe_up, hipStreamNonBlocking, mode >= 2 ? greatest : 0));
+      }
+   }
+   *run = ctx->pipe_run; *copy = ctx->pipe_copy; *up = ctx->pipe_up;
+   return 0;
+failure_return:
+   return -1;
+}
+
+void gm_batch_set_streams(gpumap_batch *b, void *run, void *copy, void *up)
+{
+   b->st_run = (hipStream_t)run; b->st_copy = (hipStream_t)copy; b->st_up = (hipStream_t)up;
+}
+
+// Waits until everything this thread has put on `st` so far is done (not for what other batches add meanwhile).
+#define GM_SYNC(b, st) do { HIP_TRY(hipEventRecord((b)->ev_sync, (st))); HIP_TRY(hipEventSynchronize((b)->ev_sync)); } while (0)
+
 // Encoding of a filled batch: the lengths seen (k_read_lengths, read back by gm_batch_fill) size the read
 // matrix; letters (or codes) -> codes in fixed-stride rows (k_encode) and the rows as bit planes (k_pack_planes).
 static int batch_encode(gpumap_ctx *ctx, gpumap_batch *b)
 {
-   hipStream_t st = b->stream;
+   hipStream_t st = b->st_run;
    const int64_t n_reads = b->n_reads;
    if (n_reads > 0) {
       HIP_TRY(hipEventSynchronize(b->ev_seen));
+      if (b->st_up != st) HIP_TRY(hipStreamWaitEvent(st, b->ev_up, 0));      // the letters are on the device
       const uint8_t *seen = b->h_small;
       GM_FAIL_IF(seen[SEEN_ERROR] != 0, "offsets must not decrease.");
       int64_t maxlen = 1;
@@ -571,13 +623,11 @@ static int batch_encode(gpumap_ctx *ctx, gpumap_batch *b)
       b->maxlen = (int)maxlen;
       HIP_TRY(b->reads.ensure((size_t)n_reads * b->stride));
       HIP_TRY(b->reads4.ensure((size_t)n_reads * (size_t)(12 * (b->stride / 32))));
-      int64_t threads = n_reads * b->stride;
-      hipLaunchKernelGGL(k_encode, dim3((unsigned)std::min<int64_t>(cdiv(threads, 256), 1 << 22)), dim3(256), 0, st,
-                         b->d_src, b->d_off, b->src_relative ? 1 : 0, n_reads, b->stride,
-                         b->src_text ? (const uint8_t *)ctx->d_sym_table : (const uint8_t *)nullptr, b->reads.as<uint8_t>());
       const int64_t groups = n_reads * (b->stride / 32);
-      hipLaunchKernelGGL(k_pack_planes, dim3((unsigned)std::min<int64_t>(cdiv(groups, 256), 1 << 20)), dim3(256), 0, st,
-                         b->reads.as<const uint8_t>(), n_reads * b->stride, (uint8_t)0xff, b->reads4.as<uint32_t>(), groups);
+      hipLaunchKernelGGL(k_encode, dim3((unsigned)std::min<int64_t>(cdiv(groups, 256), 1 << 22)), dim3(256), 0, st,
+                         b->d_src, b->d_off, b->src_relative ? 1 : 0, n_reads, b->stride,
+                         b->src_text ? (const uint8_t *)ctx->d_sym_table : (const uint8_t *)nullptr, b->reads.as<uint8_t>(),
+                         b->reads4.as<uint32_t>());
       HIP_TRY(hipGetLastError());
    } else {
       memset(b->length_seen, 0, sizeof b->length_seen);
@@ -600,7 +650,7 @@ int gm_batch_fill(gpumap_ctx *ctx, gpumap_batch *b, const void *src, const int64
    GM_FAIL_IF(n_reads >= ((int64_t)1 << 31), "too many reads in one batch.");
    HIP_TRY(hipSetDevice(ctx->device));
    {
-      hipStream_t st = b->stream;
+      hipStream_t st = b->st_up;
       b->n_reads = n_reads;
       b->ran = false; b->have_intervals = false; b->encoded = false;
       b->src_text = (src_flags & GM_SRC_TEXT) != 0;
@@ -628,9 +678,10 @@ int gm_batch_fill(gpumap_ctx *ctx, gpumap_batch *b, const void *src, const int64
          HIP_TRY(hipEventRecord(b->ev_seen, st));
       }
       if (total > 0) HIP_TRY(hipMemcpyAsync(b->up_src.p, (const uint8_t *)src + offsets[0], (size_t)total, hipMemcpyHostToDevice, st));
+      HIP_TRY(hipEventRecord(b->ev_up, st));
       if (encode_now) {
          GM_FAIL_IF(batch_encode(ctx, b) != 0, "cannot encode the batch.");
-         HIP_TRY(hipStreamSynchronize(st));             // the caller's buffers are free again
+         GM_SYNC(b, b->st_run);                         // the caller's buffers are free again
       }
    }
    return 0;
@@ -716,7 +767,7 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
    GM_FAIL_IF(tau > MAX_TAU, "argument 'tau' exceeds GPUMAP_MAX_TAU.");
    HIP_TRY(hipSetDevice(ctx->device));
    {
-      hipStream_t st = b->stream;
+      hipStream_t st = b->st_run;
       const int64_t R = b->n_reads;
       const bool compact = (result_flags & GM_RESULT_COMPACT) != 0 && !want_intervals;
       b->tau = tau; b->ran = false; b->n_hits = b->n_locs = b->n_ext = 0; b->have_intervals = false;
@@ -831,13 +882,13 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
             HIP_TRY(hipGetLastError());
          }
          HIP_TRY(hipMemcpyAsync(host_cnt, cnt, 8 * CNT_WORDS, hipMemcpyDeviceToHost, st));
-         HIP_TRY(hipStreamSynchronize(st));
+         GM_SYNC(b, st);
          GM_FAIL_IF(host_cnt[3] != 0, "search spill region overflowed (raise 'spill_nodes').");
          if (host_cnt[1] <= hit_cap) break;
          GM_FAIL_IF(attempt == 1, "hit list overflowed twice.");
          hit_cap = (size_t)host_cnt[1] + (size_t)n_waves * HIT_CHUNK;           // pieces are reserved whole, in another order next time
       }
-      unsigned long long verify_steps = 0;
+      unsigned long long verify_steps = 0, verify_windows = 0;
       const int pos_bits = ctx->ix.sar_bits;
       const int read_bits = bits_for((uint64_t)std::max<int64_t>(R, 1));
       GM_FAIL_IF(pos_bits + 4 + read_bits > 64, "batch too large for the 64-bit sort key (split the batch).");
@@ -875,8 +926,11 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
          hipLaunchKernelGGL(k_sum_steps, dim3(64), dim3(256), 0, st, b->vsteps.as<const unsigned long long>(), (int64_t)vgrid.x, cnt + CNT_WORDS);
          HIP_TRY(hipGetLastError());
          HIP_TRY(hipMemcpyAsync(host_cnt, cnt, CNT_BYTES, hipMemcpyDeviceToHost, st));
-         HIP_TRY(hipStreamSynchronize(st));
-         for (int k = 0; k < 64; k++) { host_cnt[2] += host_cnt[CNT_WORDS + k]; verify_steps += host_cnt[CNT_WORDS + k]; }
+         GM_SYNC(b, st);
+         for (int k = 0; k < 64; k++) {
+            const unsigned long long st_k = host_cnt[CNT_WORDS + k] & 0xffffffffull;
+            host_cnt[2] += st_k; verify_steps += st_k; verify_windows += host_cnt[CNT_WORDS + k] >> 32;
+         }
       }
       HIP_TRY(hipEventRecord(b->ev[1], st));
       b->n_hits = (int64_t)host_cnt[1];            // entries of the list, holes included
@@ -886,6 +940,7 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
       b->stats[4] = (int64_t)verify_steps;
       b->stats[5] = (int64_t)host_cnt[1];
       b->spill_chunks = (int64_t)host_cnt[8];
+      b->verify_windows = (int64_t)verify_windows;
 
       // ---- K3 locate: slots per entry -> scan -> every entry fills its slots
       const int64_t H = b->n_hits;
@@ -906,7 +961,7 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
          HIP_TRY(hipcub::DeviceScan::ExclusiveSum(b->cub_tmp.p, tmp, b->hit_sizes.as<int64_t>(), b->hit_off.as<int64_t>(), (int)(H + 1), st));
          int64_t *h_L = reinterpret_cast<int64_t *>(host_cnt + CNT_WORDS + 64);
          HIP_TRY(hipMemcpyAsync(h_L, b->hit_off.as<int64_t>() + H, 8, hipMemcpyDeviceToHost, st));
-         HIP_TRY(hipStreamSynchronize(st));
+         GM_SYNC(b, st);
          L = *h_L;
       }
       b->n_locs = L;
@@ -975,7 +1030,7 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
       }
       b->have_intervals = want_intervals != 0;
       HIP_TRY(hipEventRecord(b->ev[3], st));
-      HIP_TRY(hipStreamSynchronize(st));
+      GM_SYNC(b, st);
       HIP_TRY(hipEventElapsedTime(&b->ms[0], b->ev[0], b->ev[1]));
       HIP_TRY(hipEventElapsedTime(&b->ms[1], b->ev[1], b->ev[2]));
       HIP_TRY(hipEventElapsedTime(&b->ms[2], b->ev[2], b->ev[3]));
@@ -1040,7 +1095,8 @@ extern "C" int gpumap_batch_stats_ext(const gpumap_batch *b, int64_t stats[8])
    stats[2] = b->compact ? 1 : 0;
    stats[3] = (int64_t)(b->hits.cap / sizeof(Node));
    stats[4] = b->spill_chunks;
-   stats[5] = stats[6] = stats[7] = 0;
+   stats[5] = b->verify_windows;
+   stats[6] = stats[7] = 0;
    return 0;
 failure_return:
    return -1;
@@ -1103,7 +1159,7 @@ int gm_batch_fetch(gpumap_ctx *ctx, gpumap_batch *b, gpumap_hits *out, int resul
    memset(out, 0, sizeof *out);
    HIP_TRY(hipSetDevice(ctx->device));
    {
-      hipStream_t st = b->stream;
+      hipStream_t st = b->st_copy;                   // (the run has ended with a wait for its last kernel)
       const int64_t R = b->n_reads, L = b->n_locs, H = b->have_intervals ? b->n_real : 0;
       const bool compact = b->compact;               // what the run left on the device decides
       FetchDst d;
@@ -1148,7 +1204,7 @@ int gm_batch_fetch(gpumap_ctx *ctx, gpumap_batch *b, gpumap_hits *out, int resul
          rc |= fetch_array(d, &out->hit_score, b->hit_score.p, H, st);
          rc |= fetch_array(d, &out->hit_align, b->hit_align.p, 4 * H, st);
       }
-      HIP_TRY(hipStreamSynchronize(st));
+      GM_SYNC(b, st);
       GM_FAIL_IF(rc != 0, "memory error.");
    }
    return 0;

@@ -95,3 +95,7 @@ constexpr int GM_SRC_TEXT = GPUMAP_SRC_TEXT, GM_SRC_DEVICE = GPUMAP_SRC_DEVICE;
 int gm_batch_fill(gpumap_ctx *ctx, gpumap_batch *b, const void *src, const int64_t *offsets, int64_t n_reads, int src_flags, bool encode_now);
 int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, int result_flags);
 int gm_batch_fetch(gpumap_ctx *ctx, gpumap_batch *b, gpumap_hits *out, int result_flags);
+// The streams a batch puts its work on (HIP streams as void *: this header is host-only): the run's kernels,
+// the copy of the results to the host, the uploads.  A pipeline shares three streams per context among its batches.
+void gm_batch_set_streams(gpumap_batch *b, void *run, void *copy, void *up);
+int  gm_ctx_pipe_streams(gpumap_ctx *ctx, void **run, void **copy, void **up);

@@ -199,23 +199,65 @@ __global__ void __launch_bounds__(256) k_read_lengths(const int64_t *offsets, in
       if (s_seen[i]) seen[i] = 1;
 }
 
-__global__ void k_encode(const uint8_t *src, const int64_t *offsets, int relative, int64_t n_reads, int stride,
-                         const uint8_t *table /* 256 entries, or nullptr for codes */, uint8_t *dst)
+// K4: letters (or codes) of a batch -> the fixed-stride code matrix [n_reads][stride] (what k_search indexes by
+// position; 0xff behind the end of a read) AND the same rows as bit planes (what k_verify compares; see
+// k_pack_planes), in one pass: one thread per 32 symbols of a row.  src holds the letters of the batch: at
+// offsets[r] (relative = 0: the caller's device buffer), or at offsets[r] - offsets[0] (relative = 1: the
+// library's copy of the part of a host buffer the batch uses).  The letters are fetched as the aligned 32-bit
+// words that hold them (a word that holds a letter of the buffer lies inside the buffer's pages) and brought
+// into place with v_alignbit; `table` (sym_table of the index, 256 entries) sits in LDS.  table = nullptr: src
+// holds codes already (values above 4 become N, as sym_index does for characters it does not know).
+__global__ void __launch_bounds__(256) k_encode(const uint8_t *src, const int64_t *offsets, int relative, int64_t n_reads, int stride,
+                                                const uint8_t *table, uint8_t *dst, uint32_t *planes)
 {
-   // src holds the letters of the batch: at offsets[r] (relative = 0: the caller's device buffer), or at
-   // offsets[r] - offsets[0] (relative = 1: the library's copy of the part of a host buffer the batch uses).
-   // grid-stride: a launch holds fewer than 2^32 threads, a batch may hold more letters
+   __shared__ uint8_t s_tab[256];
+   if (table) s_tab[threadIdx.x] = table[threadIdx.x];
+   __syncthreads();
    const int64_t sub = relative ? offsets[0] : 0;
-   for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n_reads * stride; t += (int64_t)gridDim.x * blockDim.x) {
-      int64_t r = t / stride;
-      int p = (int)(t - r * stride);
-      int64_t beg = offsets[r], len = offsets[r + 1] - beg;
-      uint8_t code = 0xff;
-      if (p < len) {
-         uint8_t s = src[beg - sub + p];
-         code = table ? table[s] : (s < SYMS ? s : (uint8_t)UNKNOWN);
+   const int gpr = stride >> 5;                                   // groups of 32 symbols per row
+   // grid-stride: a launch holds fewer than 2^32 threads
+   for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n_reads * gpr; t += (int64_t)gridDim.x * blockDim.x) {
+      const int64_t r = t / gpr;
+      const int g = (int)(t - r * gpr);
+      const int64_t beg = offsets[r], len = offsets[r + 1] - beg;
+      int64_t k64 = len - 32 * (int64_t)g;
+      const int k = k64 < 0 ? 0 : (k64 > 32 ? 32 : (int)k64);    // letters of the read in this group
+      uint32_t c[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) c[j] = 0xffffffffu;
+      if (k > 0) {
+         const uint8_t *addr = src + (beg - sub) + 32 * g;
+         const uint32_t *base = reinterpret_cast<const uint32_t *>(reinterpret_cast<uintptr_t>(addr) & ~(uintptr_t)3);
+         const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(addr) & 3) * 8;
+         const int nd = ((int)(sh >> 3) + k + 3) >> 2;           // aligned words that hold the k letters (at most 9)
+         uint32_t w[9];
+#pragma unroll
+         for (int j = 0; j < 9; j++) w[j] = j < nd ? base[j] : 0u;
+#pragma unroll
+         for (int j = 0; j < 8; j++) {
+            const uint32_t x = __builtin_amdgcn_alignbit(w[j + 1], w[j], sh);
+            uint32_t y = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+               const uint32_t ch = (x >> (8 * q)) & 0xff;
+               uint32_t code = table ? (uint32_t)s_tab[ch] : (ch < (uint32_t)SYMS ? ch : (uint32_t)UNKNOWN);
+               if (4 * j + q >= k) code = 0xff;
+               y |= code << (8 * q);
+            }
+            c[j] = y;
+         }
       }
-      dst[t] = code;
+      uint4 *d = reinterpret_cast<uint4 *>(dst + r * stride + 32 * g);
+      d[0] = make_uint4(c[0], c[1], c[2], c[3]);
+      d[1] = make_uint4(c[4], c[5], c[6], c[7]);
+      uint32_t pl[3] = {0, 0, 0};
+#pragma unroll
+      for (int j = 0; j < 8; j++)
+#pragma unroll
+         for (int p = 0; p < 3; p++)       // bits p of four bytes -> four adjacent bits (the products' terms do not meet)
+            pl[p] |= (((((c[j] >> p) & 0x01010101u) * 0x01020408u) >> 24) & 0xfu) << (4 * j);
+      uint32_t *o = planes + 3 * t;
+      o[0] = pl[0]; o[1] = pl[1]; o[2] = pl[2];
    }
 }
 
@@ -600,10 +642,14 @@ __global__ void __launch_bounds__(256) k_verify(VerifyArgs A)
    }
    steps -= shared;
    for (int o = 32; o > 0; o >>= 1) steps += (uint32_t)__shfl_xor((int)steps, o);
-   __shared__ uint32_t s_steps[4];
-   if ((threadIdx.x & 63) == 0) s_steps[threadIdx.x >> 6] = steps;
+   const uint32_t windows = (uint32_t)__popcll(__ballot(mine));          // suffixes this wave replayed
+   __shared__ uint32_t s_steps[4], s_windows[4];
+   if ((threadIdx.x & 63) == 0) { s_steps[threadIdx.x >> 6] = steps; s_windows[threadIdx.x >> 6] = windows; }
    __syncthreads();
-   if (threadIdx.x == 0) A.n_ext[blockIdx.x] = (unsigned long long)s_steps[0] + s_steps[1] + s_steps[2] + s_steps[3];
+   // per block: steps in the low half, windows in the high half (k_sum_steps adds the words up: the halves of
+   // its 64 sums stay below 2^32 for launches of up to 2^38 steps)
+   if (threadIdx.x == 0) A.n_ext[blockIdx.x] = ((unsigned long long)s_steps[0] + s_steps[1] + s_steps[2] + s_steps[3]) |
+                                               (((unsigned long long)s_windows[0] + s_windows[1] + s_windows[2] + s_windows[3]) << 32);
 }
 
 // The steps of a k_verify launch: 64 blocks add up the per-block counts, one sum per block (what the host adds up).

@@ -1,11 +1,14 @@
 // gm_pipe.cpp -- gpumap_pipe: the chunk loop of mapper() (src/mapper.c:23-40) as a pipeline over batch objects.
-// Every slot owns a batch (own HIP stream, scratch and page-locked result arena) and a worker thread that
-// takes a chunk through stage -> run (encode + search + locate + order) -> fetch.  Slots work side by side:
-// while one slot's kernels run, another's chunk is on its way to the device and a third's results are on
-// their way back, the three transfers being asynchronous copies and kernels on different streams.  Chunks go
-// round the slots, slots go round the contexts (GPUs), results come back in submit order.
+// Every slot owns a batch (device buffers, scratch, page-locked result arena) and a worker thread that takes a
+// chunk through stage -> run (encode + search + locate + order) -> fetch.  The slots of one context share three
+// streams: uploads, kernels, result copies.  The kernels of consecutive chunks so run back to back on one
+// stream, never idle as long as two chunks are in their run (a worker only waits for events of its own
+// chunk), while the results of the chunk before and the letters of the chunk after cross the link on the
+// other two streams.  Chunks go round the slots, slots go round the contexts (GPUs), results come back in
+// submit order.
 // Host code only: the device work is behind gm_batch_fill / gm_batch_run / gm_batch_fetch (gm_device.hip).
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <thread>
@@ -45,9 +48,15 @@ static void pipe_worker(gpumap_pipe *p, Slot *s)
          if (p->stop) return;
       }
       memset(&s->hits, 0, sizeof s->hits);
+      static const bool dbg = getenv("GPUMAP_PIPE_DEBUG") != nullptr;
+      const int id = (int)(s - p->slots.data());
+      if (dbg) fprintf(stderr, "[pipe] slot %d: fill %ld reads\n", id, (long)s->n_reads);
       int rc = gm_batch_fill(s->ctx, s->batch, s->src, s->offsets, s->n_reads, p->src_flags, false);
+      if (dbg) fprintf(stderr, "[pipe] slot %d: run (rc %d)\n", id, rc);
       if (rc == 0) rc = gm_batch_run(s->ctx, s->batch, p->tau, 0, p->result_flags);
+      if (dbg) fprintf(stderr, "[pipe] slot %d: fetch (rc %d)\n", id, rc);
       if (rc == 0) rc = gm_batch_fetch(s->ctx, s->batch, &s->hits, p->result_flags);
+      if (dbg) fprintf(stderr, "[pipe] slot %d: done (rc %d)\n", id, rc);
       {
          std::lock_guard<std::mutex> l(p->m);
          s->rc = rc;
@@ -93,6 +102,9 @@ extern "C" gpumap_pipe *gpumap_pipe_create(gpumap_ctx *const *ctxs, int n_ctx, i
       s.ctx = ctxs[i % (size_t)n_ctx];                   // consecutive chunks go to different GPUs
       s.batch = gpumap_batch_new(s.ctx);
       GM_FAIL_IF(s.batch == nullptr, "cannot create a batch.");
+      void *run = nullptr, *copy = nullptr, *up = nullptr;
+      GM_FAIL_IF(gm_ctx_pipe_streams(s.ctx, &run, &copy, &up) != 0, "cannot create the streams of the pipeline.");
+      gm_batch_set_streams(s.batch, run, copy, up);
    }
    for (auto &s : p->slots) s.worker = std::thread(pipe_worker, p, &s);
    return p;

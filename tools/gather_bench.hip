@@ -126,6 +126,21 @@ static void run(const char *name, const uint4 *buf, uint64_t bytes, int waves_pe
 
 int main(int argc, char **argv)
 {
+   if (argc > 1 && !strcmp(argv[1], "quick")) {
+      // gather_bench quick <footprint MiB> [waves per CU] [steps]: one line, the quad64 shape (what k_search does)
+      // over one footprint -- the ceiling bench.py quotes beside the search kernel's request rate
+      const uint64_t mib = argc > 2 ? strtoull(argv[2], nullptr, 10) : 4096;
+      const int waves = argc > 3 ? atoi(argv[3]) : 32, qsteps = argc > 4 ? atoi(argv[4]) : 2000;
+      hipDeviceProp_t prop;
+      CK(hipGetDeviceProperties(&prop, 0));
+      uint4 *buf; uint32_t *sink;
+      CK(hipMalloc(&buf, mib << 20));
+      CK(hipMalloc(&sink, 64));
+      hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, buf, (mib << 20) / 16);
+      CK(hipDeviceSynchronize());
+      run<0>("quad64", buf, mib << 20, waves, qsteps, prop.multiProcessorCount, sink, 64, 4, 1);
+      return 0;
+   }
    int steps = argc > 1 ? atoi(argv[1]) : 2000;
    hipDeviceProp_t prop;
    CK(hipGetDeviceProperties(&prop, 0));
