@@ -27,35 +27,52 @@ def _origin_check(h, origin, strand, lens, m):
     return missing
 
 
-@pytest.mark.parametrize("total_len,n_seqs,n_reads,sample", [(300_000_000, 3, 100_000, 20_000),
-                                                           (2_200_000_000, 5, 100_000, 5_000)])
-def test_large_device_built_index(total_len, n_seqs, n_reads, sample):
-    m, tau = 100, 2
-    g, lens, _ = synth_device.make_genome(total_len, 9, n_seqs=n_seqs)
+@pytest.mark.parametrize("total_len,n_seqs,n_reads,sample,shapes", [
+    (300_000_000, 3, 100_000, 20_000, [(100, 2)]),
+    (2_200_000_000, 5, 100_000, 5_000, [(100, 2)]),
+    # BASELINE configs 4 and 5 at their full index size (n = 6 200 000 048: the bench's own index)
+    (3_100_000_000, 24, 200_000, 6_000, [(100, 2), (150, 4)])])
+def test_large_device_built_index(total_len, n_seqs, n_reads, sample, shapes):
+    g, lens, _ = synth_device.make_genome(total_len, 4 if n_seqs == 24 else 9, n_seqs=n_seqs)
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
     ctx = ma.Context.build_device(lens, 0, keep_reference=True, device_ptr=g.data_ptr())
-    reads, origin, strand = synth_device.make_reads(g, lens, n_reads, m, tau, seed=31, return_origin=True)
-    codes = reads.cpu().numpy()
-    origin, strand = origin.cpu().numpy(), strand.cpu().numpy()
-    del g, reads
-    torch.cuda.empty_cache()
-    offs = np.arange(n_reads + 1, dtype=np.int64) * m
-    h = ctx.map_batch(codes.reshape(-1), offs, tau)
-    assert (h.status == 0).all()
-    assert (h.loc_score <= tau).all()
     n = 2 * (total_len + n_seqs)
-    assert np.array_equal(h.loc_strand, (h.loc_pos >= n // 2).astype(np.uint8))
-    assert _origin_check(h, origin, strand, lens, m) == []
-    # sorted output: reads in input order, positions ascending inside a read
-    key = h.loc_read.astype(np.float64) * float(n) + h.loc_pos
-    assert (np.diff(key) > 0).all()
-    # sample against the oracle on the same index
-    ref = ctx.reference_arrays(want_text=False)
-    orc = po.Index.from_arrays(ref["occ"], ref["c"], ref["sa"], ref["sar_bits"], ref["txt_len"], ref["wil_cnt"])
-    d = orc.map_batch(codes[:sample].reshape(-1), offs[:sample + 1], tau, threads=8)
-    hs = ctx.map_batch(codes[:sample].reshape(-1), offs[:sample + 1], tau, want_intervals=True)
-    assert np.array_equal(hs.located(), d.located())
-    assert np.array_equal(hs.intervals(), d.intervals())
-    assert hs.n_ext == d.n_ext
+    batches = []
+    for m, tau in shapes:
+        reads, origin, strand = synth_device.make_reads(g, lens, n_reads, m, tau, seed=31 + m, return_origin=True)
+        batches.append((m, tau, reads.cpu().numpy(), origin.cpu().numpy(), strand.cpu().numpy()))
+        del reads
+    del g
+    torch.cuda.empty_cache()
+    orc = None
+    for m, tau, codes, origin, strand in batches:
+        offs = np.arange(n_reads + 1, dtype=np.int64) * m
+        h = ctx.map_batch(codes.reshape(-1), offs, tau)
+        assert (h.status == 0).all()
+        assert (h.loc_score <= tau).all()
+        assert np.array_equal(h.loc_strand, (h.loc_pos >= n // 2).astype(np.uint8))
+        assert _origin_check(h, origin, strand, lens, m) == []
+        # sorted output: reads in input order, positions ascending inside a read
+        key = h.loc_read.astype(np.float64) * float(n) + h.loc_pos
+        assert (np.diff(key) > 0).all()
+        # the pipeline's compact results on the same batch: same keys
+        ctx.set_option("compact_results", 1)
+        b = ctx.upload(codes.reshape(-1), offs)
+        b.run(tau)
+        hc = b.fetch()
+        b.close()
+        ctx.set_option("compact_results", 0)
+        assert np.array_equal(hc.located(), h.located()) and np.array_equal(hc.read_first_loc, h.read_first_loc)
+        # sample against the oracle on the same index
+        if orc is None:
+            ref = ctx.reference_arrays(want_text=False)
+            orc = po.Index.from_arrays(ref["occ"], ref["c"], ref["sa"], ref["sar_bits"], ref["txt_len"], ref["wil_cnt"])
+        d = orc.map_batch(codes[:sample].reshape(-1), offs[:sample + 1], tau, threads=8)
+        hs = ctx.map_batch(codes[:sample].reshape(-1), offs[:sample + 1], tau, want_intervals=True)
+        assert np.array_equal(hs.located(), d.located())
+        assert np.array_equal(hs.intervals(), d.intervals())
+        assert hs.n_ext == d.n_ext
+        hv = ctx.map_batch(codes[:sample].reshape(-1), offs[:sample + 1], tau)         # the k_verify path (what the bench times)
+        assert np.array_equal(hv.located(), d.located()) and hv.n_ext == d.n_ext
     ctx.close()
