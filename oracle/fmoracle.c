@@ -422,6 +422,98 @@ int64_t orc_blocksearch(const orc_index_t *x, const uint8_t *query, int m, int t
    return out.n;
 }
 
+/* scsearch_fw (src/blocksearch.c:314-378): seqsearch_fw restricted to extensions that stay lexicographically
+** at or below the query: while `boundary` holds (every letter so far equal to the query's), only the symbols
+** nt <= query[pos] are followed (:338), and the flag survives only through nt == query[pos] (:366).  The dash
+** at s == tau is the plain seqdash_fw (:355-358). */
+static void scsearch(sctx_t *c, const orc_hit_t *path, int pos, int end, int tau,
+                     int score_ref, int score_diff, int boundary, hitvec_t *hits)
+{
+   int64_t qv[5][3];
+   orc_extend_all(c->x, ORC_QUERY_SUFFIX, path->fp, path->rp, path->sz, qv);
+   c->n_ext++;
+   int qs = c->q[pos];
+   int lim = boundary ? qs + 1 : 5;                                  /* :338 */
+   for (int nt = 0; nt < lim; nt++) {
+      if (qv[nt][2] < 1) continue;
+      int ds = (nt != qs && qs != ORC_UNKNOWN_BASE);                 /* :345 */
+      int s  = (int)path->score + ds;
+      if (s > tau) continue;
+      orc_hit_t p = *path;
+      p.fp = qv[nt][0]; p.rp = qv[nt][1]; p.sz = qv[nt][2]; p.dp = path->dp + 1; p.score = s;
+      if (ds || qs == ORC_UNKNOWN_BASE) bit_set(&p, pos);
+      if (s == tau) {
+         if (s - score_ref >= score_diff) dash(c, p, pos + 1, end, +1, hits);
+      } else if (pos == end) {
+         if (s - score_ref >= score_diff) hv_push(c, hits, &p);
+      } else {
+         scsearch(c, &p, pos + 1, end, tau, score_ref, score_diff, boundary && nt == qs, hits);   /* :366-367 */
+      }
+   }
+}
+
+int64_t orc_scsearch(const orc_index_t *x, const orc_hit_t *start, const uint8_t *query, int pos, int end, int tau,
+                     int score_ref, int score_diff, int boundary, orc_hit_t **hits)
+{
+   sctx_t c = { x, query, 0, 0 };
+   hitvec_t out = {0};
+   scsearch(&c, start, pos, end, tau, score_ref, score_diff, boundary, &out);
+   *hits = out.v;
+   return c.err ? -1 : out.n;
+}
+
+/* blocksc_trail (src/blocksearch.c:7-103) with trail = 0, the path array `qarray` computed as its callers do
+** (one bwt_query SUFFIX per letter from the root interval: src/index_ann.c:791, test/test_blocksearch.c:49-53;
+** those steps are the caller's and are not counted in n_ext). */
+int64_t orc_blocksc(const orc_index_t *x, const uint8_t *query, int slen, int tau,
+                    orc_hit_t **hits, int64_t *n_ext)
+{
+   sctx_t c = { x, query, 0, 0 };
+   hitvec_t out = {0}, left = {0};
+   *hits = NULL;
+   if (n_ext) *n_ext = 0;
+   if (!query || slen < 1 || tau < 0) return -1;                     /* :34-39 */
+   int64_t (*qa)[3] = malloc((size_t)(slen + 1) * sizeof *qa);
+   if (!qa) return -1;
+   qa[0][0] = 0; qa[0][1] = 0; qa[0][2] = x->txt_len;               /* bwt_new_query, src/index_bwt.c:48-52 */
+   for (int i = 0; i < slen; i++) {
+      int64_t qv[5][3];
+      orc_extend_all(x, ORC_QUERY_SUFFIX, qa[i][0], qa[i][1], qa[i][2], qv);
+      memcpy(qa[i + 1], qv[query[i]], sizeof qv[0]);
+   }
+   int last_fragment = qa[slen][0] >= qa[slen][1];                   /* :55 */
+   int tau_arg = tau;
+   int n_cnt = 0;
+   for (int i = 0; i < slen && n_cnt <= tau; i++) n_cnt += query[i] == ORC_UNKNOWN_BASE;   /* :59-60 */
+   tau -= n_cnt;
+   if (tau < 0 || (tau == 0 && !last_fragment)) { free(qa); return 0; }                     /* :63-66 */
+   /* The tree comes from the caller's alloc_stack_tree(tau) (src/index_ann.c:541-543, test/test_blocksearch.c:38): for
+   ** tau = 0 it is a single node without a left subtree, and the left search returns -1 (:74 -> :123). */
+   if (tau_arg == 0) { free(qa); return -1; }
+   int pos_r = slen / 2 + (last_fragment ? slen % 2 : 0);            /* :69 */
+   int tau_l = tau / 2 - (last_fragment ? 0 : (1 - tau % 2));        /* :70 */
+   int rc = 0;
+   if (0 < pos_r) rc = block_rec(&c, 0, pos_r - 1, tau_l + 1, &left);   /* :73-74 (trail = 0): an empty left block is not searched, a fresh tree holds no hits */
+   if (rc == 0) {
+      int64_t max_sa_pos = qa[pos_r][0] + qa[pos_r][2];              /* :76 */
+      int64_t i = 0;
+      while (i < left.n) {                                            /* :77-85: out-of-boundary hits go, the last one takes the slot */
+         if (left.v[i].fp < max_sa_pos) i++;
+         else left.v[i] = left.v[--left.n];
+      }
+      for (i = 0; i < left.n; i++)                                    /* :89-92 */
+         scsearch(&c, &left.v[i], pos_r, slen - 1, tau, (int)left.v[i].score, 0, 1, &out);
+      if (n_cnt)
+         for (i = 0; i < out.n; i++) out.v[i].score += n_cnt;        /* :95-97 */
+   }
+   free(left.v);
+   free(qa);
+   if (n_ext) *n_ext = c.n_ext;
+   if (rc != 0 || c.err) { free(out.v); return -1; }
+   *hits = out.v;
+   return out.n;
+}
+
 int64_t orc_seqsearch(const orc_index_t *x, int dir, const orc_hit_t *start, const uint8_t *query,
                       int pos, int end, int tau, int score_ref, int score_diff, orc_hit_t **hits)
 {
@@ -440,6 +532,7 @@ typedef struct {
    const int64_t *offsets;
    int64_t beg, end;
    int tau;
+   int sc;              /* 0: blocksearch_trail_rec per read, 1: blocksc_trail per read */
    int64_t *status;
    int64_t n_hits, n_locs, cap_hits, cap_locs, n_ext;
    int64_t *hits, *locs;
@@ -453,7 +546,10 @@ static void *batch_worker(void *arg)
       int64_t m = j->offsets[r + 1] - j->offsets[r];
       orc_hit_t *h = NULL;
       int64_t ext = 0;
-      int64_t nh = (m >= 1 && m <= 256) ? orc_blocksearch(j->x, j->codes + j->offsets[r], (int)m, j->tau, &h, &ext) : -1;
+      int64_t nh = -1;
+      if (m >= 1 && m <= 256)
+         nh = j->sc ? orc_blocksc(j->x, j->codes + j->offsets[r], (int)m, j->tau, &h, &ext)
+                    : orc_blocksearch(j->x, j->codes + j->offsets[r], (int)m, j->tau, &h, &ext);
       if (nh < 0) { j->status[r] = -1; continue; }   /* steps of a failed search are not counted */
       j->n_ext += ext;
       j->status[r] = 0;
@@ -483,8 +579,23 @@ static void *batch_worker(void *arg)
    return NULL;
 }
 
+static orc_batch_t *batch_run(const orc_index_t *x, const uint8_t *codes, const int64_t *offsets,
+                              int64_t n_reads, int tau, int threads, int sc);
+
 orc_batch_t *orc_map_batch(const orc_index_t *x, const uint8_t *codes, const int64_t *offsets,
                            int64_t n_reads, int tau, int threads)
+{
+   return batch_run(x, codes, offsets, n_reads, tau, threads, 0);
+}
+
+orc_batch_t *orc_blocksc_batch(const orc_index_t *x, const uint8_t *codes, const int64_t *offsets,
+                               int64_t n_reads, int tau, int threads)
+{
+   return batch_run(x, codes, offsets, n_reads, tau, threads, 1);
+}
+
+static orc_batch_t *batch_run(const orc_index_t *x, const uint8_t *codes, const int64_t *offsets,
+                              int64_t n_reads, int tau, int threads, int sc)
 {
    if (threads < 1) threads = 1;
    if (threads > n_reads) threads = n_reads > 0 ? (int)n_reads : 1;
@@ -496,7 +607,7 @@ orc_batch_t *orc_map_batch(const orc_index_t *x, const uint8_t *codes, const int
    struct timespec t0, t1;
    clock_gettime(CLOCK_MONOTONIC, &t0);
    for (int t = 0; t < threads; t++) {
-      jobs[t].x = x; jobs[t].codes = codes; jobs[t].offsets = offsets; jobs[t].tau = tau;
+      jobs[t].x = x; jobs[t].codes = codes; jobs[t].offsets = offsets; jobs[t].tau = tau; jobs[t].sc = sc;
       jobs[t].status = b->status;
       jobs[t].beg = n_reads * t / threads; jobs[t].end = n_reads * (t + 1) / threads;
       pthread_create(&tid[t], NULL, batch_worker, &jobs[t]);

@@ -88,6 +88,19 @@ int64_t orc_blocksearch(const orc_index_t *idx, const uint8_t *query, int m, int
 int64_t orc_seqsearch(const orc_index_t *idx, int dir, const orc_hit_t *start, const uint8_t *query,
                       int pos, int end, int tau, int score_ref, int score_diff, orc_hit_t **hits);
 
+/* blocksc_trail(query, qarray, slen, tau, 0, tree), src/blocksearch.c:7-103, with scsearch_fw (:314-378): the
+** "seeq & construct" search of ann_build_mt (src/index_ann.c:556-567): neighbours of the query that are
+** lexicographically at or below it, query N lowering tau.  qarray is computed inside as the callers do.
+** Hits in the reference's order; -1 where the reference returns -1. */
+int64_t orc_blocksc(const orc_index_t *idx, const uint8_t *query, int slen, int tau,
+                    orc_hit_t **hits, int64_t *n_ext);
+/* scsearch_fw from an arbitrary start path (the KATs of test/test_blocksearch.c:497-594). */
+int64_t orc_scsearch(const orc_index_t *idx, const orc_hit_t *start, const uint8_t *query, int pos, int end, int tau,
+                     int score_ref, int score_diff, int boundary, orc_hit_t **hits);
+/* orc_map_batch with orc_blocksc in place of orc_blocksearch. */
+orc_batch_t *orc_blocksc_batch(const orc_index_t *idx, const uint8_t *codes, const int64_t *offsets,
+                               int64_t n_reads, int tau, int threads);
+
 /* Whole batch, read-parallel with `threads` pthreads (static partition, private scratch; the
 ** model is ann_build_mt, src/index_ann.c:500-609).  codes: concatenated symbol codes,
 ** offsets[n_reads+1]. */

@@ -76,6 +76,14 @@ def lib():
         L.orc_map_batch.restype = C.POINTER(_OrcBatch)
         L.orc_map_batch.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_int64),
                                     C.c_int64, C.c_int, C.c_int]
+        L.orc_blocksc_batch.restype = C.POINTER(_OrcBatch)
+        L.orc_blocksc_batch.argtypes = L.orc_map_batch.argtypes
+        L.orc_blocksc.restype = C.c_int64
+        L.orc_blocksc.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_int, C.c_int,
+                                  C.POINTER(C.POINTER(OrcHit)), C.POINTER(C.c_int64)]
+        L.orc_scsearch.restype = C.c_int64
+        L.orc_scsearch.argtypes = [C.c_void_p, C.POINTER(OrcHit), C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int,
+                                   C.c_int, C.c_int, C.c_int, C.POINTER(C.POINTER(OrcHit))]
         L.orc_batch_free.argtypes = [C.POINTER(_OrcBatch)]
         L._libc = C.CDLL(None)
         L._libc.free.argtypes = [C.c_void_p]
@@ -240,12 +248,39 @@ class Index:
         lib()._libc.free(C.cast(hp, C.c_void_p))
         return res
 
-    def map_batch(self, codes, offsets, tau, threads=1):
+    def scsearch(self, start, codes, pos, end, tau, score_ref=0, score_diff=0, boundary=1):
+        q = np.ascontiguousarray(codes, dtype=np.uint8)
+        st = OrcHit(start.get("fp", 0), start.get("rp", 0), start.get("sz", self.txt_len),
+                    start.get("dp", 0), start.get("score", 0), (C.c_uint64 * 4)(*start.get("align", [0] * 4)))
+        hp = C.POINTER(OrcHit)()
+        n = lib().orc_scsearch(self._h, C.byref(st), q.ctypes.data_as(C.POINTER(C.c_uint8)),
+                               pos, end, tau, score_ref, score_diff, boundary, C.byref(hp))
+        res = self._hits_to_list(hp, n)
+        lib()._libc.free(C.cast(hp, C.c_void_p))
+        return res
+
+    def blocksc(self, codes, tau):
+        """blocksc_trail(q, qarray, slen, tau, 0, tree): list of hits in reference order, or None on error."""
+        q = np.ascontiguousarray(codes, dtype=np.uint8)
+        hp = C.POINTER(OrcHit)()
+        next_ = C.c_int64(0)
+        n = lib().orc_blocksc(self._h, q.ctypes.data_as(C.POINTER(C.c_uint8)), len(q), tau,
+                              C.byref(hp), C.byref(next_))
+        if n < 0:
+            return None
+        res = self._hits_to_list(hp, n)
+        lib()._libc.free(C.cast(hp, C.c_void_p))
+        return res
+
+    def blocksc_batch(self, codes, offsets, tau, threads=1):
+        return self.map_batch(codes, offsets, tau, threads, _fn="orc_blocksc_batch")
+
+    def map_batch(self, codes, offsets, tau, threads=1, _fn="orc_map_batch"):
         codes = np.ascontiguousarray(codes, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.int64)
         n_reads = len(offsets) - 1
         cp = codes.ctypes.data_as(C.POINTER(C.c_uint8)) if len(codes) else C.POINTER(C.c_uint8)()
-        bp = lib().orc_map_batch(self._h, cp, offsets.ctypes.data_as(C.POINTER(C.c_int64)),
+        bp = getattr(lib(), _fn)(self._h, cp, offsets.ctypes.data_as(C.POINTER(C.c_int64)),
                                  n_reads, tau, threads)
         b = bp.contents
         status = np.ctypeslib.as_array(b.status, shape=(max(n_reads, 1),))[:n_reads].copy()

@@ -16,6 +16,11 @@
 ** Commands
 **   ref_driver build <ref.fa> <base>                 index_build() -> base.{sym,txt,sar,bwt}
 **   ref_driver map   <base> <reads.txt> <tau> <out.bin> [threads]
+**   ref_driver sc    <base> <kmers.txt> <tau> <out.bin>   blocksc_trail(q, qarray, slen, tau, 0, tree) per line
+**                                                    (src/blocksearch.c:7-103; qarray as test/test_blocksearch.c:49-53)
+**   ref_driver sctrail <base> <kmers.txt> <tau> <out.bin> the same, driven as ann_build_mt drives it
+**                                                    (src/index_ann.c:556-567, :786-825): a tree and a previous query
+**                                                    per strand class, trail = letters shared with that query
 **   ref_driver kat   <out.txt>                       dumps answers of the reference's own
 **                                                    primitives on literal texts (used to
 **                                                    cross-check tests/golden/kat_*.json)
@@ -51,6 +56,7 @@ typedef struct {
    char    **reads;
    int64_t   beg, end;
    int       tau;
+   int       mode;     /* 0 map (blocksearch_trail_rec), 1 sc (blocksc_trail, trail 0), 2 sctrail (as ann_build_mt) */
    int64_t  *status;
    out_t     out;
    int       rc;
@@ -75,11 +81,55 @@ static int out_reserve(out_t *o, int64_t nh, int64_t nl)
    return 0;
 }
 
+/* The search of one line: 0 / -1 as the reference returns; *used = the tree that holds the hits. */
+static int search_one(job_t *j, uint8_t *q, int m, pstree_t **trees, uint8_t **prev, int *prev_len, pstree_t **used)
+{
+   *used = trees[0];
+   if (j->mode == 0)
+      return blocksearch_trail_rec(q, 0, m - 1, j->tau + 1, 0, j->index->bwt, trees[0]);
+   /* the path array of the callers of blocksc_trail: one bwt_query SUFFIX per letter from the root interval */
+   bwtquery_t **qa = calloc((size_t)m + 1, sizeof *qa);
+   int rc = 0;
+   qa[0] = bwt_new_query(j->index->bwt);
+   for (int i = 0; i < m && rc == 0; i++) {
+      qa[i + 1] = bwt_new_query(j->index->bwt);
+      if (bwt_query(q[i], BWT_QUERY_SUFFIX, qa[i], qa[i + 1]) == -1) rc = -1;
+   }
+   if (rc == 0) {
+      int cls = 0, trail = 0;
+      if (j->mode == 2) {
+         /* as neigh_next (src/index_ann.c:786-825): the class is the strand test, the trail the letters shared with
+         ** the last query of that class */
+         cls = bwt_start(qa[m]) >= bwt_rcstart(qa[m]);
+         while (trail < m && trail < prev_len[cls] && prev[cls][trail] == q[trail]) trail++;
+         if (trail >= m) trail = 0;         /* the same k-mer twice: ann_build_mt never asks again, search afresh */
+         memcpy(prev[cls], q, (size_t)m);
+         prev_len[cls] = m;
+      }
+      if (j->mode == 1) {
+         /* every line on a fresh tree: with trail = 0 blocksc_trail still skips the left search when the left block
+         ** is empty (pos_r = 0, src/blocksearch.c:73) and would extend what the line before left in the tree */
+         free_stack_tree(trees[0]);
+         trees[0] = alloc_stack_tree(j->tau);
+         if (trees[0] == NULL) rc = -1;
+      }
+      *used = trees[cls];
+      if (rc == 0) rc = blocksc_trail(q, qa, m, j->tau, trail, trees[cls]);
+      if (rc == -1 && j->mode == 2) prev_len[cls] = 0;
+   }
+   for (int i = 0; i <= m; i++) free(qa[i]);
+   free(qa);
+   return rc;
+}
+
 static void *map_worker(void *arg)
 {
    job_t *j = (job_t *)arg;
-   pstree_t *tree = alloc_stack_tree(j->tau);
-   if (tree == NULL) { j->rc = -1; return NULL; }
+   pstree_t *trees[2] = { alloc_stack_tree(j->tau), alloc_stack_tree(j->tau) };
+   uint8_t *prev[2] = { calloc(257, 1), calloc(257, 1) };
+   int prev_len[2] = { 0, 0 };
+   pstree_t *tree = trees[0];
+   if (trees[0] == NULL || trees[1] == NULL) { j->rc = -1; return NULL; }
    for (int64_t r = j->beg; r < j->end; r++) {
       char *read = j->reads[r];
       int m = (int)strlen(read);
@@ -89,13 +139,14 @@ static void *map_worker(void *arg)
       if (m < 1 || m > 256) { j->status[r] = -1; continue; }
       uint8_t *q = sym_str_index(read, j->index->sym);
       if (q == NULL) { j->rc = -1; break; }
-      if (blocksearch_trail_rec(q, 0, m - 1, j->tau + 1, 0, j->index->bwt, tree) == -1) {
+      if (search_one(j, q, m, trees, prev, prev_len, &tree) == -1) {
          /* e.g. more blocks than letters: src/blocksearch.c:126 */
          j->status[r] = -1;
          free(q);
          /* The tree may hold partial results of inner calls: drop and rebuild it. */
+         int which = tree == trees[1];
          free_stack_tree(tree);
-         tree = alloc_stack_tree(j->tau);
+         trees[which] = tree = alloc_stack_tree(j->tau);
          if (tree == NULL) { j->rc = -1; break; }
          continue;
       }
@@ -122,7 +173,8 @@ static void *map_worker(void *arg)
       }
       free(q);
    }
-   free_stack_tree(tree);
+   free_stack_tree(trees[0]); free_stack_tree(trees[1]);
+   free(prev[0]); free(prev[1]);
    return NULL;
 }
 
@@ -151,13 +203,13 @@ static double now_s(void)
    return ts.tv_sec + 1e-9 * ts.tv_nsec;
 }
 
-static int cmd_map(int argc, char **argv)
+static int cmd_map(int argc, char **argv, int mode)
 {
    if (argc < 6) return 2;
    const char *base = argv[2], *rfile = argv[3], *ofile = argv[5];
    int tau = atoi(argv[4]);
    int threads = argc > 6 ? atoi(argv[6]) : 1;
-   if (threads < 1) threads = 1;
+   if (threads < 1 || mode == 2) threads = 1;          /* the trail depends on the order of the lines */
 
    index_t *index = index_read((char *)base);
    if (index == NULL) { fprintf(stderr, "ref_driver: cannot read index %s\n", base); return 1; }
@@ -171,7 +223,7 @@ static int cmd_map(int argc, char **argv)
    pthread_t *tid = calloc(threads, sizeof(pthread_t));
    double t0 = now_s();
    for (int t = 0; t < threads; t++) {
-      jobs[t].index = index; jobs[t].reads = reads; jobs[t].tau = tau; jobs[t].status = status;
+      jobs[t].index = index; jobs[t].reads = reads; jobs[t].tau = tau; jobs[t].status = status; jobs[t].mode = mode;
       jobs[t].beg = n_reads * t / threads;
       jobs[t].end = n_reads * (t + 1) / threads;
       pthread_create(&tid[t], NULL, map_worker, &jobs[t]);
@@ -263,7 +315,9 @@ static int cmd_kat(int argc, char **argv)
 int main(int argc, char **argv)
 {
    if (argc >= 2 && strcmp(argv[1], "build") == 0) return cmd_build(argc, argv);
-   if (argc >= 2 && strcmp(argv[1], "map") == 0) return cmd_map(argc, argv);
+   if (argc >= 2 && strcmp(argv[1], "map") == 0) return cmd_map(argc, argv, 0);
+   if (argc >= 2 && strcmp(argv[1], "sc") == 0) return cmd_map(argc, argv, 1);
+   if (argc >= 2 && strcmp(argv[1], "sctrail") == 0) return cmd_map(argc, argv, 2);
    if (argc >= 2 && strcmp(argv[1], "kat") == 0) return cmd_kat(argc, argv);
    fprintf(stderr, "usage: ref_driver build <ref.fa> <base> | map <base> <reads.txt> <tau> <out.bin> [threads]"
                    " | kat <spec> <out.txt>\n");
