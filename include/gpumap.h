@@ -218,6 +218,17 @@ typedef struct {
 int  gpumap_map_batch(gpumap_ctx *ctx, const uint8_t *codes, const int64_t *offsets,
                       int64_t n_reads, int tau, int want_intervals, gpumap_hits *out);
 void gpumap_hits_free(gpumap_hits *hits);
+/* blocksc_trail(query, qarray, slen, tau, 0, tree) (src/blocksearch.c:7-103, with scsearch_fw :314-378) for a batch
+** of queries: the search ann_build_mt runs for every k-mer of the text (src/index_ann.c:556-567): the neighbours of the
+** query that are lexicographically at or below it, every query N lowering tau by one.  The path array the reference's
+** callers compute (one bwt_query SUFFIX per letter, src/index_ann.c:791) is computed on the device.  `trail`, the
+** caller's reuse of the last query's left block, is not needed: every query is searched afresh, which gives the same
+** hits (tests/test_oracle_blocksc.py).  out: status[q] (0 / -1 as blocksc_trail returns; -1 also for tau = 0 on the
+** last strand class, where the reference's one-node tree fails), hit_* = tree->stack (score with the N count added,
+** :94-97) sorted by (query, fp), loc_* = their suffix-array entries.  At most 256 / (2 (tau + 1)) distinct query
+** lengths per batch. */
+int  gpumap_blocksc_batch(gpumap_ctx *ctx, const uint8_t *codes, const int64_t *offsets, int64_t n_queries,
+                          int tau, gpumap_hits *out);
 
 /* The same in three steps, so that a caller can keep batches resident in HBM and time the
 ** device work alone (bench.py): upload -> run (search + locate + sort, results stay on the

@@ -81,6 +81,7 @@ API = {
     "gpumap_encode": (_I, [_P, _P, _P, _I64, _P]),
     "gpumap_map_batch": (_I, [_P, _P, _P, _I64, _I, _I, C.POINTER(_Hits)]),
     "gpumap_hits_free": (None, [C.POINTER(_Hits)]),
+    "gpumap_blocksc_batch": (_I, [_P, _P, _P, _I64, _I, C.POINTER(_Hits)]),
     "gpumap_batch_upload": (_P, [_P, _P, _P, _I64]),
     "gpumap_batch_upload_text": (_P, [_P, _P, _P, _I64]),
     "gpumap_batch_refill_text": (_I, [_P, _P, _P, _P, _I64]),
@@ -496,6 +497,17 @@ class Context:
         if lib().gpumap_map_batch(self._h, _ptr(codes), _ptr(offsets), len(offsets) - 1, tau, int(want_intervals),
                                   C.byref(raw)) != 0:
             raise GpumapError("gpumap_map_batch failed (see stderr)")
+        h = Hits(raw)
+        lib().gpumap_hits_free(C.byref(raw))
+        return h
+
+    def blocksc_batch(self, codes, offsets, tau):
+        """blocksc_trail (trail 0) for a batch of queries: interval hits + located hits."""
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        raw = _Hits()
+        if lib().gpumap_blocksc_batch(self._h, _ptr(codes), _ptr(offsets), len(offsets) - 1, tau, C.byref(raw)) != 0:
+            raise GpumapError("gpumap_blocksc_batch failed (see stderr)")
         h = Hits(raw)
         lib().gpumap_hits_free(C.byref(raw))
         return h

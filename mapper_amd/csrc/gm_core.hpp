@@ -169,6 +169,9 @@ constexpr int META_DASH = 6, META_SCORE = 7, META_SREF = 10, META_FW = 13, META_
 // a node whose interval holds one suffix and that k_verify finishes against the text (the list entry
 // stays as it is; what becomes of it goes to the locate stage as a sort key).
 constexpr int META_CAND = 31;
+// The search of blocksc_trail (k_search<true>, no k_verify there): bit 31 of a node inside the bounded extension = every
+// letter of the extension so far equals the query's (`boundary` of scsearch_fw, src/blocksearch.c:338, :366).
+constexpr int META_BOUND = 31;
 
 constexpr int PHASE_FINAL = 63;
 
@@ -258,6 +261,36 @@ inline bool build_phase_table(int m, int tau, uint32_t *table, uint8_t *lo = nul
    if (b.error) return false;
    for (int i = 0; i < 3 * tau + 1; i++) { table[i] = b.entry[i]; if (lo) lo[i] = b.lo[i]; }
    return true;
+}
+
+// blocksc_trail (src/blocksearch.c:7-103) as a phase table: the block search of the left part query[0, pos_r) with
+// tau_l + 1 blocks (:74), whose hits continue into ONE more phase, the lexicographically bounded forward extension
+// over [pos_r, slen) with up to tau_eff mismatches in all (scsearch_fw, :89-92).  tau_eff = tau - (N in the query),
+// last = the query's interval lies at or behind its reverse complement's (:55).  Phases 0..3*tau_l as
+// build_phase_table(pos_r, tau_l) gives them, phase 3*tau_l + 1 the bounded extension.  Returns 0 = search,
+// 1 = no search and no hits (:64-66; an empty left block: :73), -1 = where the reference returns -1 (and for an
+// empty right part, where it reads behind the query).
+constexpr int SC_SEARCH = 0, SC_NO_HITS = 1, SC_ERROR = -1;
+inline int build_sc_phase_table(int slen, int tau_arg, int tau_eff, int last, uint32_t *table, uint8_t *lo, int *sc_phase, int *leaves)
+{
+   *sc_phase = 0; *leaves = 0;
+   if (slen < 1 || slen > MAX_READ) return SC_ERROR;
+   if (tau_eff < 0 || (tau_eff == 0 && !last)) return SC_NO_HITS;                  // :64-66
+   if (tau_arg == 0) return SC_ERROR;               // the caller's tree, alloc_stack_tree(0), has no left subtree (:74 -> :123)
+   const int pos_r = slen / 2 + (last ? slen % 2 : 0);                             // :69
+   const int tau_l = tau_eff / 2 - (last ? 0 : (1 - tau_eff % 2));                 // :70
+   if (pos_r > slen - 1) return SC_ERROR;
+   if (pos_r == 0) return SC_NO_HITS;                                              // :73 with trail = 0
+   PhaseBuilder b;
+   b.tau_total = tau_l;
+   const int scp = 3 * tau_l + 1;
+   b.build(0, pos_r - 1, tau_l + 1, scp);
+   if (b.error) return SC_ERROR;
+   for (int i = 0; i < scp; i++) { table[i] = b.entry[i]; lo[i] = b.lo[i]; }
+   table[scp] = phase_entry(pos_r, slen - 1, 1, tau_eff, 0, PHASE_FINAL);         // :91
+   lo[scp] = 0;
+   *sc_phase = scp; *leaves = tau_l + 1;
+   return SC_SEARCH;
 }
 
 GM_HD void enter_phase(NodeR &n, int phase, uint32_t e)

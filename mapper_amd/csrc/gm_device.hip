@@ -43,6 +43,7 @@ struct gpumap_batch {
    DevBuf loc_read, loc_pos, loc_fwd, loc_seq, loc_seqpos, loc_strand, loc_score;
    DevBuf hkeys, hkeys_alt, hidx, hidx_alt, hit_read, hit_fp, hit_rp, hit_sz, hit_dp, hit_score, hit_align;
    DevBuf spill, counters, cub_tmp;
+   DevBuf read_row, sc_bound, score_add, row_leaves, row_state;      // blocksc_trail (gm_batch_run with GM_RUN_SC)
    const unsigned long long *sorted_keys = nullptr;     // the located hits' keys after the sort (in keys or keys_alt)
    int key_pos_bits = 0;
    bool compact = false;             // the last run left keys + CSR offsets only (no structure of arrays)
@@ -66,7 +67,7 @@ struct gpumap_batch {
       for (DevBuf *b : {&up_src, &up_off, &seen, &reads, &reads4, &read_len, &len_row, &row_len, &phases, &phase_rec, &phase_lo, &status, &hits, &hit_sizes, &hit_off, &direct, &vsteps, &longer, &keys, &keys_alt,
                         &read_cnt, &read_first, &loc_read, &loc_pos, &loc_fwd, &loc_seq, &loc_seqpos, &loc_strand,
                         &loc_score, &hkeys, &hkeys_alt, &hidx, &hidx_alt, &hit_read, &hit_fp, &hit_rp, &hit_sz,
-                        &hit_dp, &hit_score, &hit_align, &spill, &counters, &cub_tmp})
+                        &hit_dp, &hit_score, &hit_align, &spill, &counters, &cub_tmp, &read_row, &sc_bound, &score_add, &row_leaves, &row_state})
          b->release();
       for (auto &e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
       for (hipEvent_t *e : {&ev_seen, &ev_sync, &ev_up}) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
@@ -775,13 +776,47 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
       // ---- K4 (a staged batch): letters -> codes -> bit planes, inside the timed region
       HIP_TRY(hipEventRecord(b->ev[5], st));
       if (!b->encoded) GM_FAIL_IF(batch_encode(ctx, b) != 0, "cannot encode the batch.");
-      // ---- schedule: one phase-table row per read length present (src/blocksearch.c:138-170)
+      // ---- schedule: one phase-table row per read length present (src/blocksearch.c:138-170); for blocksc_trail
+      // one per (length, tau - N count, strand class) (src/blocksearch.c:55-70)
+      const bool sc = (result_flags & GM_RUN_SC) != 0;
       std::vector<uint16_t> len_row(MAX_READ + 1, NO_ROW);
       std::vector<uint32_t> phases, phase_rec;
-      std::vector<uint8_t> phase_lo;
+      std::vector<uint8_t> phase_lo, row_leaves, row_state;
       std::vector<uint16_t> row_len;
       int rows = 0;
-      for (int m = 1; m <= MAX_READ; m++) {
+      if (sc) {
+         int n_len = 0;
+         for (int m = 1; m <= MAX_READ; m++) if (b->length_seen[m]) n_len++;
+         GM_FAIL_IF(n_len * (tau + 1) * 2 > 256, "too many distinct query lengths for one batch of blocksc_trail searches.");
+         for (int m = 1; m <= MAX_READ; m++) {
+            if (!b->length_seen[m]) continue;
+            len_row[m] = (uint16_t)(rows / ((tau + 1) * 2));
+            for (int te = 0; te <= tau; te++)
+               for (int last = 0; last < 2; last++) {
+                  uint32_t tab[MAX_PHASES];
+                  uint8_t lo_tab[MAX_PHASES];
+                  memset(tab, 0, sizeof tab);
+                  memset(lo_tab, 0, sizeof lo_tab);
+                  int scp = 0, leaves = 0;
+                  const int st = build_sc_phase_table(m, tau, te, last, tab, lo_tab, &scp, &leaves);
+                  rows++;
+                  row_len.push_back((uint16_t)m);
+                  row_leaves.push_back((uint8_t)leaves);
+                  row_state.push_back((uint8_t)(st == SC_SEARCH ? 0 : (st == SC_NO_HITS ? 1 : 2)));
+                  phases.insert(phases.end(), tab, tab + MAX_PHASES);
+                  phase_lo.insert(phase_lo.end(), lo_tab, lo_tab + MAX_PHASES);
+                  for (int p = 0; p < MAX_PHASES; p++) {
+                     uint32_t x = 0, y = 0;
+                     if (st == SC_SEARCH && p <= scp) {
+                        phase_record(tab, p, x, y);
+                        if (phase_next(tab[p]) == scp) y |= 1u << 9;        // a hit of the left block enters the bounded extension
+                     }
+                     phase_rec.push_back(x); phase_rec.push_back(y);
+                  }
+               }
+         }
+      }
+      for (int m = 1; m <= MAX_READ && !sc; m++) {
          if (!b->length_seen[m]) continue;
          uint32_t tab[MAX_PHASES];
          uint8_t lo_tab[MAX_PHASES];
@@ -801,7 +836,7 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
       if (phases.empty()) { phases.assign(MAX_PHASES, 0); phase_rec.assign(2 * MAX_PHASES, 0); phase_lo.assign(MAX_PHASES, 0); }
       if (row_len.empty()) row_len.push_back(0);
       {
-         SmallStage ss{b->h_small + 512, H_SMALL_BYTES - 512 - 1024};                               // (the first bytes hold the lengths seen)
+         SmallStage ss{b->h_small + 512, H_SMALL_BYTES - 512 - 1024 - 1024};                               // (the first bytes hold the lengths seen)
          const uint16_t *h_len_row = ss.put(len_row);
          const uint32_t *h_phases = ss.put(phases), *h_rec = ss.put(phase_rec);
          const uint8_t *h_lo = ss.put(phase_lo);
@@ -818,7 +853,26 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
          HIP_TRY(hipMemcpyAsync(b->row_len.p, h_row_len, 2 * row_len.size(), hipMemcpyHostToDevice, st));
          HIP_TRY(hipMemcpyAsync(b->phases.p, h_phases, 4 * phases.size(), hipMemcpyHostToDevice, st));
       }
-      if (R > 0) {
+      if (sc) {
+         if (row_leaves.empty()) { row_leaves.push_back(0); row_state.push_back(1); }
+         SmallStage s2{b->h_small + 512 + (H_SMALL_BYTES - 512 - 1024) - 1024, 1024};      // (the last KiB of the staging block: 2 x 256 bytes)
+         const uint8_t *h_leaves = s2.put(row_leaves), *h_state = s2.put(row_state);
+         GM_FAIL_IF(!h_leaves || !h_state, "row tables do not fit the staging block.");
+         HIP_TRY(b->row_leaves.ensure(row_leaves.size()));
+         HIP_TRY(b->row_state.ensure(row_state.size()));
+         HIP_TRY(b->read_row.ensure(2 * (size_t)std::max<int64_t>(R, 1)));
+         HIP_TRY(b->sc_bound.ensure(8 * (size_t)std::max<int64_t>(R, 1)));
+         HIP_TRY(b->score_add.ensure((size_t)std::max<int64_t>(R, 1)));
+         HIP_TRY(hipMemcpyAsync(b->row_leaves.p, h_leaves, row_leaves.size(), hipMemcpyHostToDevice, st));
+         HIP_TRY(hipMemcpyAsync(b->row_state.p, h_state, row_state.size(), hipMemcpyHostToDevice, st));
+      }
+      if (R > 0 && sc) {
+         hipLaunchKernelGGL(k_sc_prepare, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, st, ctx->ix, b->reads.as<const uint8_t>(),
+                            b->read_len.as<const uint16_t>(), b->len_row.as<const uint16_t>(), b->row_state.as<const uint8_t>(), R,
+                            b->stride, tau, b->read_row.as<uint16_t>(), b->sc_bound.as<int64_t>(), b->score_add.as<uint8_t>(),
+                            b->status.as<int64_t>());
+         HIP_TRY(hipGetLastError());
+      } else if (R > 0) {
          hipLaunchKernelGGL(k_status, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, st, b->read_len.as<const uint16_t>(),
                             b->len_row.as<const uint16_t>(), R, b->status.as<int64_t>());
          HIP_TRY(hipGetLastError());
@@ -829,7 +883,8 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
       // the text and can cost a workgroup per CU), unless the option asks for a number
       const size_t search_lds = (size_t)ctx->ix.n_super * SYMS * 8;
       int resident_wg = 0;
-      HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident_wg, k_search, WG_THREADS, search_lds));
+      if (sc) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident_wg, k_search<true>, WG_THREADS, search_lds));
+      else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident_wg, k_search<false>, WG_THREADS, search_lds));
       if (getenv("GPUMAP_VERBOSE")) fprintf(stderr, "k_search: %d workgroups of %d waves resident per CU (dynamic LDS %zu B)\n", resident_wg, WG_WAVES, search_lds);
       // 16 waves per CU where four workgroups fit (texts below 2.2 G symbols: the table is small) and the batch
       // is large enough (small batches start and drain faster with 12).  At GRCh38 size 12 and 16 waves run
@@ -849,7 +904,7 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
       // -1 (default): 2 for texts of 2^31 symbols and more, else 1 (measured: pairs pay where most k-mers of
       // the jump table's length occur more than once; +8 % at GRCh38 size, -13 % at chr21 size)
       const int verify_mode = ctx->verify >= 0 ? ctx->verify : (ctx->ix.n >= ((int64_t)1 << 31) ? 2 : 1);
-      const int use_verify = (verify_mode && ctx->d_text != nullptr && ctx->d_text4 != nullptr && !want_intervals) ? verify_mode : 0;
+      const int use_verify = (verify_mode && ctx->d_text != nullptr && ctx->d_text4 != nullptr && !want_intervals && !sc) ? verify_mode : 0;
       // first guess of the list's length (a batch that is run or refilled again keeps the longer list): with
       // k_verify every seed can leave a candidate, plus what repeats add (5.5 entries per read at GRCh38
       // size, tau 2); too short costs a second run of the search.  Option "hit_list_guess" overrides (tests).
@@ -872,13 +927,17 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
          A.spill = b->spill.as<Node>(); A.spill_cap = (uint32_t)ctx->spill_cap; A.error = (int *)(cnt + 3); A.stats = cnt + 4;
          A.jump = (const uint4 *)ctx->d_jump; A.jump_k = ctx->jump_k;
          A.verify = use_verify;
+         A.read_row = sc ? b->read_row.as<const uint16_t>() : nullptr;
+         A.sc_bound = sc ? b->sc_bound.as<const int64_t>() : nullptr;
+         A.row_leaves = sc ? b->row_leaves.as<const uint8_t>() : nullptr;
          {
             const int rpr = 64 / (tau + 1);
             int64_t k = R / std::max<int64_t>(1, n_waves * 8 * rpr);           // at least 8 reservations per wave: balance at the end
             A.cursor_chunk = (uint32_t)(rpr * std::min<int64_t>(16, std::max<int64_t>(1, k)));
          }
          if (R > 0) {
-            hipLaunchKernelGGL(k_search, dim3((unsigned)n_wg), dim3(WG_THREADS), search_lds, st, A);
+            if (sc) hipLaunchKernelGGL(k_search<true>, dim3((unsigned)n_wg), dim3(WG_THREADS), search_lds, st, A);
+            else hipLaunchKernelGGL(k_search<false>, dim3((unsigned)n_wg), dim3(WG_THREADS), search_lds, st, A);
             HIP_TRY(hipGetLastError());
          }
          HIP_TRY(hipMemcpyAsync(host_cnt, cnt, 8 * CNT_WORDS, hipMemcpyDeviceToHost, st));
@@ -976,10 +1035,11 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
          hipLaunchKernelGGL(k_place, dim3((unsigned)cdiv(H, 256)), dim3(256), 0, st, ctx->ix, b->hits.as<const Node>(), H,
                             verified ? b->direct.as<const unsigned long long>() : (const unsigned long long *)nullptr,
                             b->hit_sizes.as<const int64_t>(), b->hit_off.as<const int64_t>(), pos_bits, b->keys.as<unsigned long long>(),
-                            b->longer.as<unsigned int>(), n_longer, longer_cap);
+                            b->longer.as<unsigned int>(), n_longer, longer_cap, sc ? b->score_add.as<const uint8_t>() : (const uint8_t *)nullptr);
          hipLaunchKernelGGL(k_place_long, dim3((unsigned)(4 * ctx->cu_count)), dim3(256), 0, st, ctx->ix, b->hits.as<const Node>(),
                             b->hit_sizes.as<const int64_t>(), b->hit_off.as<const int64_t>(), pos_bits, b->keys.as<unsigned long long>(),
-                            b->longer.as<const unsigned int>(), (const unsigned int *)n_longer);
+                            b->longer.as<const unsigned int>(), (const unsigned int *)n_longer,
+                            sc ? b->score_add.as<const uint8_t>() : (const uint8_t *)nullptr);
          HIP_TRY(hipGetLastError());
       }
       HIP_TRY(hipEventRecord(b->ev[2], st));
@@ -1025,7 +1085,8 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
          hipLaunchKernelGGL(k_unpack_hits, dim3((unsigned)cdiv(std::max<int64_t>(b->n_real, 1), 256)), dim3(256), 0, st, b->hits.as<const Node>(),
                             (const unsigned int *)dv.Current(), b->n_real, b->reads.as<const uint8_t>(), b->read_len.as<const uint16_t>(),
                             b->stride, b->hit_read.as<int64_t>(), b->hit_fp.as<int64_t>(), b->hit_rp.as<int64_t>(),
-                            b->hit_sz.as<int64_t>(), b->hit_dp.as<int64_t>(), b->hit_score.as<int64_t>(), b->hit_align.as<uint64_t>());
+                            b->hit_sz.as<int64_t>(), b->hit_dp.as<int64_t>(), b->hit_score.as<int64_t>(), b->hit_align.as<uint64_t>(),
+                            sc ? b->score_add.as<const uint8_t>() : (const uint8_t *)nullptr);
          HIP_TRY(hipGetLastError());
       }
       b->have_intervals = want_intervals != 0;
@@ -1253,6 +1314,27 @@ extern "C" int gpumap_hits_expand(const gpumap_ctx *ctx, gpumap_hits *h)
    }
    return 0;
 failure_return:
+   return -1;
+}
+
+// blocksc_trail for a batch of queries (k-mers): src/blocksearch.c:7-103 with trail = 0 for every query, the path array
+// its callers hand over computed on the device (k_sc_prepare).  Interval hits and located hits, as gpumap_map_batch
+// with want_intervals gives them for blocksearch_trail_rec.
+extern "C" int gpumap_blocksc_batch(gpumap_ctx *ctx, const uint8_t *codes, const int64_t *offsets, int64_t n_queries,
+                                    int tau, gpumap_hits *out)
+{
+   gpumap_batch *b = nullptr;
+   GM_FAIL_IF(out == nullptr, "argument 'out' is NULL.");
+   memset(out, 0, sizeof *out);
+   GM_FAIL_IF(ctx == nullptr, "argument 'ctx' is NULL.");
+   b = gpumap_batch_upload(ctx, codes, offsets, n_queries);
+   GM_FAIL_IF(b == nullptr, "cannot upload the batch.");
+   GM_FAIL_IF(gm_batch_run(ctx, b, tau, 1, GM_RUN_SC) != 0, "batch failed.");
+   GM_FAIL_IF(gm_batch_fetch(ctx, b, out, 0) != 0, "cannot fetch results.");
+   gpumap_batch_free(b);
+   return 0;
+failure_return:
+   gpumap_batch_free(b);
    return -1;
 }
 

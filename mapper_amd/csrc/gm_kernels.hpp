@@ -329,7 +329,59 @@ struct SearchArgs {
    int jump_k;
    int verify;                  // nodes with sz <= verify (0, 1 or 2) leave as candidates for k_verify
    uint32_t cursor_chunk;       // reads a wave reserves per atomic on the cursor (a multiple of its refill)
+   // k_search<true> (blocksc_trail): per query its row of the phase tables (NO_ROW: not searched) and the bound of the
+   // left block's hits (src/blocksearch.c:76), per row its number of leaf phases
+   const uint16_t *read_row;
+   const int64_t  *sc_bound;
+   const uint8_t  *row_leaves;
 };
+
+// blocksc_trail's set-up for every query of a batch (src/blocksearch.c:46-70 and what its callers compute before it,
+// src/index_ann.c:783-813, test/test_blocksearch.c:49-53): the path array by one bwt_query SUFFIX per letter from the
+// root interval (N as the literal symbol it is there), of which the search needs the interval of the whole query (its
+// strand class `last_fragment`, :55) and the end of the left block's interval (the bound of :76); the N count that
+// lowers tau (:59-63).  Row of the phase tables = ((row of the length) * (tau + 1) + tau_eff) * 2 + last; the host has
+// built every row and knows which are not searched (row_state: 0 search, 1 no hits, 2 error).
+__global__ void __launch_bounds__(256) k_sc_prepare(IndexDev ix, const uint8_t *reads, const uint16_t *read_len, const uint16_t *len_row,
+                                                    const uint8_t *row_state, int64_t n_reads, int stride, int tau,
+                                                    uint16_t *read_row, int64_t *sc_bound, uint8_t *score_add, int64_t *status)
+{
+   const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+   if (r >= n_reads) return;
+   const int m = read_len[r];
+   read_row[r] = NO_ROW; sc_bound[r] = 0; score_add[r] = 0;
+   if (m < 1 || m > MAX_READ) { status[r] = -1; return; }             // :37; longer than the mismatch bitmap (src/blocksearch.h:12-13)
+   uint64_t c[SYMS];
+   for (int j = 0; j < SYMS; j++) c[j] = ix.tables[TAB_C + j];
+   const uint8_t *q = reads + r * stride;
+   int64_t fp = 0, rp = 0, sz = ix.n;                                  // bwt_new_query
+   int64_t end_lo = 0, end_hi = 0;                                     // fp + sz after m/2 and after m/2 + m%2 letters
+   int n_cnt = 0;
+   const int cut_lo = m / 2, cut_hi = m / 2 + m % 2;
+   for (int i = 0; i < m; i++) {
+      const int s = q[i];
+      n_cnt += s == UNKNOWN;
+      int64_t occ0[SYMS], occ1[SYMS], fpn[SYMS], rpn[SYMS], szn[SYMS];
+      // bwt_query(s, BWT_QUERY_SUFFIX): the backward step on the reverse complement's side (src/index_bwt.c:234-238, :280-286)
+      rank_abs(ix, rp, occ0);
+      rank_abs(ix, rp + sz, occ1);
+      extend_all(fp, sz, occ0, occ1, c, fpn, rpn, szn);
+      const int js = complement(s);
+      fp = rpn[js]; rp = fpn[js]; sz = szn[js];
+      if (i + 1 == cut_lo) end_lo = fp + sz;
+      if (i + 1 == cut_hi) end_hi = fp + sz;
+   }
+   const int last = fp >= rp;                                           // :55
+   if (n_cnt > tau) { status[r] = 0; return; }                          // :63-66: tau < 0
+   const int tau_eff = tau - n_cnt;
+   const int row = (len_row[m] * (tau + 1) + tau_eff) * 2 + last;
+   const int state = row_state[row];
+   status[r] = state == 2 ? -1 : 0;
+   if (state != 0) return;
+   read_row[r] = (uint16_t)row;
+   sc_bound[r] = last ? end_hi : end_lo;                                // qarray[pos_r], pos_r = m/2 + (last ? m%2 : 0) (:69, :76)
+   score_add[r] = (uint8_t)n_cnt;                                       // :94-97
+}
 
 // ------------------------------------------------------------------------------------------------
 // k_verify: the rest of the search of a node whose interval holds ONE suffix.  From there on the
@@ -758,7 +810,8 @@ __global__ void k_hit_sizes(const Node *hits, int64_t n_hits, int64_t *sizes)
 
 __global__ void __launch_bounds__(256) k_place(IndexDev ix, const Node *hits, int64_t n_hits, const unsigned long long *direct,
                                                const int64_t *sizes, const int64_t *hit_off, int pos_bits,
-                                               unsigned long long *keys, unsigned int *longer, unsigned int *n_longer, unsigned int longer_cap)
+                                               unsigned long long *keys, unsigned int *longer, unsigned int *n_longer, unsigned int longer_cap,
+                                               const uint8_t *score_add /* per read (blocksc_trail adds the N count, :94-97) or nullptr */)
 {
    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
    if (i >= n_hits) return;
@@ -781,13 +834,14 @@ __global__ void __launch_bounds__(256) k_place(IndexDev ix, const Node *hits, in
    NodeR h;
    unpack_node(hits[i], h);
    const int64_t off = hit_off[i];
-   const unsigned long long hi = ((unsigned long long)h.read << (pos_bits + 4)) | (unsigned long long)h.score;
+   const unsigned long long hi = ((unsigned long long)h.read << (pos_bits + 4)) | (unsigned long long)(h.score + (score_add ? score_add[h.read] : 0));
    for (int64_t j = 0; j < sz; j++)
       keys[off + j] = hi | ((unsigned long long)sa_entry(ix.sa, ix.sar_bits, h.fp + j) << 4);
 }
 
 __global__ void __launch_bounds__(256) k_place_long(IndexDev ix, const Node *hits, const int64_t *sizes, const int64_t *hit_off, int pos_bits,
-                                                    unsigned long long *keys, const unsigned int *longer, const unsigned int *n_longer)
+                                                    unsigned long long *keys, const unsigned int *longer, const unsigned int *n_longer,
+                                                    const uint8_t *score_add)
 {
    const unsigned int n = *n_longer;
    for (unsigned int e = blockIdx.x; e < n; e += gridDim.x) {
@@ -795,7 +849,7 @@ __global__ void __launch_bounds__(256) k_place_long(IndexDev ix, const Node *hit
       NodeR h;
       unpack_node(hits[i], h);
       const int64_t off = hit_off[i], sz = sizes[i];
-      const unsigned long long hi = ((unsigned long long)h.read << (pos_bits + 4)) | (unsigned long long)h.score;
+      const unsigned long long hi = ((unsigned long long)h.read << (pos_bits + 4)) | (unsigned long long)(h.score + (score_add ? score_add[h.read] : 0));
       for (int64_t j = threadIdx.x; j < sz; j += blockDim.x)    // consecutive threads read consecutive packed entries
          keys[off + j] = hi | ((unsigned long long)sa_entry(ix.sa, ix.sar_bits, h.fp + j) << 4);
    }
@@ -846,7 +900,7 @@ __global__ void k_hit_keys(const Node *hits, int64_t n_hits, unsigned long long 
 __global__ void k_unpack_hits(const Node *hits, const unsigned int *idx, int64_t n_hits, const uint8_t *reads,
                               const uint16_t *read_len, int stride, int64_t *hit_read, int64_t *hit_fp,
                               int64_t *hit_rp, int64_t *hit_sz, int64_t *hit_dp, int64_t *hit_score,
-                              uint64_t *hit_align_out)
+                              uint64_t *hit_align_out, const uint8_t *score_add)
 {
    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
    if (i >= n_hits) return;
@@ -855,7 +909,7 @@ __global__ void k_unpack_hits(const Node *hits, const unsigned int *idx, int64_t
    int m = read_len[h.read];
    hit_read[i] = h.read; hit_fp[i] = h.fp; hit_rp[i] = h.rp; hit_sz[i] = h.sz;
    hit_dp[i] = m;                       // one extension per letter (dp + 1 per bwt_query_all)
-   hit_score[i] = h.score;
+   hit_score[i] = h.score + (score_add ? score_add[h.read] : 0);
    uint64_t al[4];
    hit_align(h.mm, h.score, reads + (size_t)h.read * stride, m, al);
    for (int w = 0; w < 4; w++) hit_align_out[4 * i + w] = al[w];

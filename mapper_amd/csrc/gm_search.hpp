@@ -136,6 +136,11 @@ __device__ __forceinline__ void pin(uint4 &v) { asm volatile("" : "+v"(v.x), "+v
 
 constexpr int PH_LDS_ROWS = 8;       // phase-record rows (read lengths) kept in LDS; others are read from global memory
 
+// SC = the search of blocksc_trail (src/blocksearch.c:7-103): the schedule of a query is the block search of its
+// left part followed by one bounded forward extension (build_sc_phase_table); a hit of the left part only goes on if
+// it starts below the bound of the query's own left block (:76-85); inside the extension a node on the boundary
+// follows the symbols up to the query's only (scsearch_fw, :338) and stays on it through the query's symbol (:366).
+template <bool SC>
 __global__ void __launch_bounds__(WG_THREADS) k_search(SearchArgs A)
 {
    __shared__ Node s_q[WG_WAVES][QCAP];
@@ -224,8 +229,9 @@ __global__ void __launch_bounds__(WG_THREADS) k_search(SearchArgs A)
                   if (mk) {
                      uint32_t rd = (uint32_t)(base + r);
                      int m = A.read_len[rd];
-                     int row = m <= MAX_READ ? A.len_row[m] : NO_ROW;
+                     int row = SC ? A.read_row[rd] : (m <= MAX_READ ? A.len_row[m] : NO_ROW);
                      mk = row != NO_ROW;
+                     if (SC && mk) mk = leaf < (int)A.row_leaves[row];          // tau_l + 1 leaves, by the query's class and N count
                      if (mk) {
                         NodeR sd;
                         sd.fp = 0; sd.rp = 0; sd.sz = A.ix.n;        // bwt_new_query, src/index_bwt.c:48-52
@@ -337,7 +343,8 @@ __global__ void __launch_bounds__(WG_THREADS) k_search(SearchArgs A)
       uint32_t alive = (szn[0] >= 1 ? 1u : 0u) | (szn[1] >= 1 ? 2u : 0u) | (szn[2] >= 1 ? 4u : 0u) |
                        (szn[3] >= 1 ? 8u : 0u) | (szn[4] >= 1 ? 16u : 0u);
       if (fw) alive = (__brev(alive & 15u) >> 28) | (alive & 16u);
-      uint32_t cand = have ? valid_children(meta, pos, qc, alive) & (0x1fu << first) : 0u;
+      uint32_t cand = have ? valid_children(SC ? meta & ~(1u << META_BOUND) : meta, pos, qc, alive) & (0x1fu << first) : 0u;
+      if (SC && ((meta >> META_BOUND) & 1) && !((meta >> META_DASH) & 1)) cand &= (2u << qc) - 1u;      // nt <= query[pos] (:338)
 
       // ------------------------------------------------------------ this pass follows the first candidate;
       // the others stay behind as a continuation of the same node (re-extended when it is popped)
@@ -368,17 +375,25 @@ __global__ void __launch_bounds__(WG_THREADS) k_search(SearchArgs A)
          uint32_t meta_n;
          const bool done = child_meta(meta, pos, qc, nt, mm, meta_n, mm);
          meta = meta_n;
+         if (SC && nt != qc) meta &= ~(1u << META_BOUND);                        // off the boundary (:366)
          pos = fw ? pos + 1 : pos - 1;
          if (done) {
             const int idx = (int)(mm >> 56) * MAX_PHASES + (int)(meta & 63);
             const uint2 rec = idx < PH_LDS_ROWS * MAX_PHASES ? s_ph[idx] : A.phase_rec[idx];
-            if (rec.y >> 8) {
+            if ((rec.y >> 8) & 1) {
                emit = true;
                pos = 0;
+               if (SC) meta &= ~(1u << META_BOUND);
             } else {
                const uint32_t s = (meta >> META_SCORE) & 7;
                meta = rec.x | (s << META_SCORE) | (s << META_SREF);
-               pos = (int)rec.y;
+               pos = (int)(rec.y & 255);
+               if (SC && ((rec.y >> 9) & 1)) {
+                  // a hit of the left block enters the bounded extension: those at or beyond the end of the query's
+                  // own left block are dropped (:76-85), the others start on the boundary (:91)
+                  if (fp >= A.sc_bound[read]) have = false;
+                  meta |= 1u << META_BOUND;
+               }
             }
          }
       } else {

@@ -491,6 +491,9 @@ int64_t orc_blocksc(const orc_index_t *x, const uint8_t *query, int slen, int ta
    ** tau = 0 it is a single node without a left subtree, and the left search returns -1 (:74 -> :123). */
    if (tau_arg == 0) { free(qa); return -1; }
    int pos_r = slen / 2 + (last_fragment ? slen % 2 : 0);            /* :69 */
+   /* an empty right part (one letter, last fragment): scsearch_fw (:91) would read query[slen], undefined in the
+   ** reference; reported as an error here and by the HIP path */
+   if (pos_r > slen - 1) { free(qa); return -1; }
    int tau_l = tau / 2 - (last_fragment ? 0 : (1 - tau % 2));        /* :70 */
    int rc = 0;
    if (0 < pos_r) rc = block_rec(&c, 0, pos_r - 1, tau_l + 1, &left);   /* :73-74 (trail = 0): an empty left block is not searched, a fresh tree holds no hits */
