@@ -29,5 +29,5 @@ done
 python3 $R/tools/profile_summary.py $raw > $final/summary.json || exit 1
 [ -z "$PMC_ONLY" ] && cp $raw/stats/*/*kernel_stats.csv $final/kernel_stats.csv
 cp $raw/*.json $final/ 2>/dev/null
-for d in $raw/pmc*/; do n=$(basename $d); head -1 $d/*/*counter_collection.csv > $final/$n.counters.csv; grep -E "k_search|k_verify" $d/*/*counter_collection.csv >> $final/$n.counters.csv; done
+for d in $raw/pmc*/; do n=$(basename $d); head -1 $d/*/*counter_collection.csv > $final/$n.counters.csv; grep -E "k_search|k_verify|k_place|k_encode" $d/*/*counter_collection.csv >> $final/$n.counters.csv; done
 cat $final/summary.json

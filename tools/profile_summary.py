@@ -8,13 +8,13 @@ def main(root):
     for f in glob.glob(os.path.join(root, "stats", "**", "*kernel_stats.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             name = r["Name"]
-            if "gm::" in name:
-                out["kernel_stats"].append({"kernel": name.split("(")[0], "calls": int(r["Calls"]),
+            if "gm::" in name or "rocprim" in name or "rocclr" in name:
+                out["kernel_stats"].append({"kernel": name.split("(")[0][:90], "calls": int(r["Calls"]),
                                             "avg_ns": float(r["AverageNs"]), "pct": float(r["Percentage"])})
     for f in sorted(glob.glob(os.path.join(root, "pmc*", "**", "*counter_collection.csv"), recursive=True)):
         acc = {}
         for r in csv.DictReader(open(f)):
-            if "k_search" not in r["Kernel_Name"] and "k_verify" not in r["Kernel_Name"]:
+            if not any(k in r["Kernel_Name"] for k in ("k_search", "k_verify", "k_place", "k_encode", "k_read_first", "Onesweep", "onesweep")):
                 continue
             key = (r["Kernel_Name"].split("(")[0], r["Counter_Name"])
             d = acc.setdefault(key, {})
