@@ -310,6 +310,27 @@ void         gpumap_pipe_release(gpumap_pipe *pipe, gpumap_hits *hits);
 void         gpumap_pipe_destroy(gpumap_pipe *pipe);
 
 /* ------------------------------------------------------------------------------------------
+** Several GPUs (no counterpart in the reference, which never leaves one CPU).  n_members replicas of
+** the index, member i on GPU devices[i] (devices == NULL: GPUs 0 .. n_members-1).  The index is uploaded and
+** repacked once, on the first member's GPU; the other GPUs receive the device arrays by ncclBroadcast (RCCL over
+** xGMI; librccl.so is loaded only then); members that share a GPU with an earlier member adopt its arrays (several
+** members on one GPU: tests).  gpumap_multi_map_batch is gpumap_map_batch with the reads split into contiguous ranges
+** in input order, one host thread per member, the hit lists concatenated in member order: the output of one GPU.
+** gpumap_multi_ctxs gives the members to gpumap_pipe_create / gpumap_mapper_multi (chunks go round the GPUs).
+** ---------------------------------------------------------------------------------------- */
+typedef struct gpumap_multi gpumap_multi;
+gpumap_multi *gpumap_create_multi(const gpumap_index_view *view, int n_members, const int *devices);
+/* The same around an existing context (e.g. of gpumap_build_device), which becomes member 0 and stays the caller's. */
+gpumap_multi *gpumap_multi_from_ctx(gpumap_ctx *root, int root_device, int n_members, const int *devices);
+int           gpumap_multi_size(const gpumap_multi *multi);
+int           gpumap_multi_used_rccl(const gpumap_multi *multi);   /* 1: the arrays went through ncclBroadcast */
+gpumap_ctx   *gpumap_multi_ctx(const gpumap_multi *multi, int i);
+gpumap_ctx *const *gpumap_multi_ctxs(const gpumap_multi *multi);
+int           gpumap_multi_map_batch(gpumap_multi *multi, const uint8_t *codes, const int64_t *offsets, int64_t n_reads,
+                                     int tau, int want_intervals, gpumap_hits *out);
+void          gpumap_multi_destroy(gpumap_multi *multi);
+
+/* ------------------------------------------------------------------------------------------
 ** mapper() (src/mapper.c:3-47, src/mapper.h:10): reads `qfile` (FASTQ / FASTA / raw, detected
 ** as io_stream_set_parser does, src/io.c:232-266) in chunks, maps each chunk on the GPU and
 ** writes one line per located hit to `out_path` (NULL or "-" = stdout):

@@ -73,6 +73,14 @@ API = {
     "gpumap_devindex_header_size": (C.c_size_t, []),
     "gpumap_devindex_export": (_I, [_P, C.POINTER(DevIndex), _P]),
     "gpumap_create_from_device": (_P, [C.POINTER(DevIndex), _P, _I]),
+    "gpumap_create_multi": (_P, [C.POINTER(IndexView), _I, _P]),
+    "gpumap_multi_from_ctx": (_P, [_P, _I, _I, _P]),
+    "gpumap_multi_size": (_I, [_P]),
+    "gpumap_multi_used_rccl": (_I, [_P]),
+    "gpumap_multi_ctx": (_P, [_P, _I]),
+    "gpumap_multi_ctxs": (C.POINTER(_P), [_P]),
+    "gpumap_multi_map_batch": (_I, [_P, _P, _P, _I64, _I, _I, C.POINTER(_Hits)]),
+    "gpumap_multi_destroy": (None, [_P]),
     "gpumap_occ_all": (_I, [_P, _I64, _P, _P]),
     "gpumap_query_all": (_I, [_P, _I, _I64, _P, _P, _P, _P]),
     "gpumap_query_all_noalloc": (_I, [_P, _I, _I64, _P, _P, _P, _P]),
@@ -305,6 +313,71 @@ class Batch:
             pass
 
 
+class Multi:
+    """gpumap_multi: replicas of one index on several GPUs (or several members on one GPU)."""
+
+    def __init__(self, handle):
+        if not handle:
+            raise GpumapError("gpumap_multi could not be created (see stderr)")
+        self._h = handle
+
+    @classmethod
+    def from_index(cls, index, n_members, devices=None):
+        d = np.ascontiguousarray(devices, dtype=np.int32) if devices is not None else None
+        return cls(lib().gpumap_create_multi(C.byref(index.view), n_members, _ptr(d) if d is not None else None))
+
+    @classmethod
+    def from_ctx(cls, ctx, n_members, devices=None, root_device=0):
+        d = np.ascontiguousarray(devices, dtype=np.int32) if devices is not None else None
+        m = cls(lib().gpumap_multi_from_ctx(ctx._h, root_device, n_members, _ptr(d) if d is not None else None))
+        m._root = ctx
+        return m
+
+    def __len__(self):
+        return lib().gpumap_multi_size(self._h)
+
+    @property
+    def used_rccl(self):
+        return bool(lib().gpumap_multi_used_rccl(self._h))
+
+    def members(self):
+        """The members as Context objects that do not own their handles."""
+        out = []
+        for i in range(len(self)):
+            c = Context.__new__(Context)
+            c._h, c._keep, c._borrowed = lib().gpumap_multi_ctx(self._h, i), self, True
+            out.append(c)
+        return out
+
+    def map_batch(self, codes, offsets, tau, want_intervals=False):
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        raw = _Hits()
+        if lib().gpumap_multi_map_batch(self._h, _ptr(codes), _ptr(offsets), len(offsets) - 1, tau, int(want_intervals),
+                                        C.byref(raw)) != 0:
+            raise GpumapError("gpumap_multi_map_batch failed (see stderr)")
+        h = Hits(raw)
+        lib().gpumap_hits_free(C.byref(raw))
+        return h
+
+    def mapper(self, qfile, index, tau, out_path):
+        rc = lib().gpumap_mapper_multi(os.fsencode(qfile), index._h, lib().gpumap_multi_ctxs(self._h), len(self), tau,
+                                       os.fsencode(out_path) if out_path else None)
+        if rc != 0:
+            raise GpumapError("gpumap_mapper_multi failed (see stderr)")
+
+    def close(self):
+        if self._h:
+            lib().gpumap_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Pipe:
     """gpumap_pipe: chunks in, results out in the same order, the stages of consecutive chunks overlapping."""
 
@@ -519,9 +592,9 @@ class Context:
             raise GpumapError("gpumap_mapper failed (see stderr)")
 
     def close(self):
-        if self._h:
+        if self._h and not getattr(self, "_borrowed", False):
             lib().gpumap_destroy(self._h)
-            self._h = None
+        self._h = None
 
     def __del__(self):
         try:

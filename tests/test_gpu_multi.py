@@ -1,0 +1,76 @@
+"""Several GPUs behind the C-ABI (gpumap_multi) on a box with one GPU: G members share the device ("test
+without 8 GPUs: logical sharding on 1 device must give byte-identical concatenated output for G in {1,2,4,8}"), and
+the RCCL path (dlopen of librccl, ncclCommInitAll, grouped ncclBroadcast of the four arrays) is driven on a
+communicator of one rank.  Results are compared with one context's, which test_gpu_parity.py compares with the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+import mapper_amd as ma
+from mapper_amd import synth
+from tests import common
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def setup(workdir):
+    base, seqs = common.synth_index(workdir, "rep400k", 400_000, seed=31, n_seqs=2, repeat_rich=True)
+    hix = ma.HostIndex.read(base)
+    ctx = ma.Context.from_index(hix, 0)
+    codes, offs = synth.make_reads(seqs, 9001, 100, 2, seed=77, n_frac=0.01)
+    want = ctx.map_batch(codes.reshape(-1), offs, 2, want_intervals=True)
+    yield base, hix, ctx, codes.reshape(-1), offs, want
+    ctx.close()
+
+
+@pytest.mark.parametrize("g", [1, 2, 4, 8])
+def test_members_on_one_device_give_the_output_of_one_gpu(setup, g):
+    base, hix, ctx, codes, offs, want = setup
+    m = ma.Multi.from_index(hix, g, devices=[0] * g)
+    assert len(m) == g and not m.used_rccl
+    for intervals in (True, False):
+        h = m.map_batch(codes, offs, 2, want_intervals=intervals)
+        assert np.array_equal(h.status, want.status)
+        assert np.array_equal(h.read_first_loc, want.read_first_loc)
+        for k in ("loc_read", "loc_pos", "loc_fwd", "loc_seq", "loc_seqpos", "loc_strand", "loc_score"):
+            assert np.array_equal(getattr(h, k), getattr(want, k)), k
+        assert h.n_ext == want.n_ext
+        if intervals:
+            assert np.array_equal(h.intervals(), want.intervals())
+    # fewer reads than members, and none
+    h = m.map_batch(codes[:300], offs[:4], 2)
+    assert np.array_equal(h.located(), ctx.map_batch(codes[:300], offs[:4], 2).located())
+    assert m.map_batch(np.zeros(0, np.uint8), np.zeros(1, np.int64), 2).n_locs == 0
+    m.close()
+
+
+def test_rccl_broadcast_path_on_one_rank(setup, monkeypatch):
+    base, hix, ctx, codes, offs, want = setup
+    monkeypatch.setenv("GPUMAP_MULTI_FORCE_RCCL", "1")
+    m = ma.Multi.from_ctx(ctx, 2, devices=[0, 0])
+    assert m.used_rccl                      # librccl loaded, communicator made, the four arrays broadcast (in place)
+    h = m.map_batch(codes, offs, 2)
+    assert np.array_equal(h.located(), want.located()) and h.n_ext == want.n_ext
+    m.close()
+    # the root context is the caller's and still works
+    assert np.array_equal(ctx.map_batch(codes, offs, 2).located(), want.located())
+
+
+def test_mapper_over_members_writes_what_one_gpu_writes(setup, workdir, monkeypatch):
+    base, hix, ctx, codes, offs, want = setup
+    fq = os.path.join(workdir, "multi.fq")
+    with open(fq, "w") as f:
+        for r in range(len(offs) - 1):
+            s = synth.codes_to_text(codes[offs[r]:offs[r + 1]]).decode()
+            f.write("@r%d\n%s\n+\n%s\n" % (r, s, "I" * len(s)))
+    monkeypatch.setenv("GPUMAP_CHUNK_BYTES", "150000")          # many chunks going round the members
+    one = os.path.join(workdir, "multi_one.txt")
+    ctx.mapper(fq, hix, 2, one)
+    m = ma.Multi.from_ctx(ctx, 3, devices=[0, 0, 0])
+    out = os.path.join(workdir, "multi_three.txt")
+    m.mapper(fq, hix, 2, out)
+    assert open(out, "rb").read() == open(one, "rb").read()
+    assert os.path.getsize(one) > 100000
+    m.close()
