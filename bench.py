@@ -202,6 +202,9 @@ def main():
         d_chunks.append(to_letters(rd))
         del rd
     offs = np.arange(w["reads"] + 1, dtype=np.int64) * w["m"]
+    # N > 1: one small sample that every rank maps against its own replica (the same reads on every rank)
+    sample = synth_device.make_reads(g, lens, min(20000, w["reads"]), w["m"], w["tau"], seed=w["seed"] * 1000 + 5).cpu().numpy() \
+        if world > 1 else None
     del g
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
@@ -275,8 +278,8 @@ def main():
     # replicas: every rank maps the same small sample; the checksums of the sorted keys must agree
     replica = None
     if world > 1:
-        ns = min(20000, n_reads)
-        h = ctx.map_batch(codes[:ns].reshape(-1), offs[:ns + 1], w["tau"])
+        ns = len(sample)
+        h = ctx.map_batch(sample.reshape(-1), offs[:ns + 1], w["tau"])
         mine = np.array([int(h.n_locs), int(np.bitwise_xor.reduce(h.located().reshape(-1) * np.int64(0x9E3779B97F4A7C15 >> 1))) if h.n_locs else 0],
                         dtype=np.int64)
         allv = [torch.zeros(2, dtype=torch.int64, device="cuda") for _ in range(world)]
