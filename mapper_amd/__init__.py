@@ -299,7 +299,7 @@ class Batch:
         if lib().gpumap_batch_stats_ext(self._h, st) != 0:
             raise GpumapError("gpumap_batch_stats_ext failed")
         return dict(attempts=st[0], us_encode=st[1], compact=st[2], hit_list_capacity=st[3], spill_chunks=st[4],
-                    verify_windows=st[5])
+                    verify_windows=st[5], big_candidates=st[6])
 
     def close(self):
         if self._h:

@@ -44,12 +44,14 @@ struct gpumap_batch {
    DevBuf hkeys, hkeys_alt, hidx, hidx_alt, hit_read, hit_fp, hit_rp, hit_sz, hit_dp, hit_score, hit_align;
    DevBuf spill, counters, cub_tmp;
    DevBuf read_row, sc_bound, score_add, row_leaves, row_state;      // blocksc_trail (gm_batch_run with GM_RUN_SC)
+   DevBuf big_idx, big_cnt, big_off, big_dense, big_keys, vsteps2;   // candidates of three and four suffixes (k_verify_group)
    const unsigned long long *sorted_keys = nullptr;     // the located hits' keys after the sort (in keys or keys_alt)
    int key_pos_bits = 0;
    bool compact = false;             // the last run left keys + CSR offsets only (no structure of arrays)
    bool length_seen[MAX_READ + 1];
    int64_t n_hits = 0, n_real = 0, n_locs = 0, n_ext = 0;
    int64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+   int64_t n_big = 0;                // candidates of three and four suffixes in the last run
    int64_t verify_windows = 0;       // suffixes k_verify replayed on the text in the last run
    int64_t spill_chunks = 0;         // chunks of SPILL_CHUNK nodes the deques of the last search moved to global memory
    int attempts = 0;                 // searches the last run took (2: the first guess of the hit list was too short)
@@ -67,7 +69,8 @@ struct gpumap_batch {
       for (DevBuf *b : {&up_src, &up_off, &seen, &reads, &reads4, &read_len, &len_row, &row_len, &phases, &phase_rec, &phase_lo, &status, &hits, &hit_sizes, &hit_off, &direct, &vsteps, &longer, &keys, &keys_alt,
                         &read_cnt, &read_first, &loc_read, &loc_pos, &loc_fwd, &loc_seq, &loc_seqpos, &loc_strand,
                         &loc_score, &hkeys, &hkeys_alt, &hidx, &hidx_alt, &hit_read, &hit_fp, &hit_rp, &hit_sz,
-                        &hit_dp, &hit_score, &hit_align, &spill, &counters, &cub_tmp, &read_row, &sc_bound, &score_add, &row_leaves, &row_state})
+                        &hit_dp, &hit_score, &hit_align, &spill, &counters, &cub_tmp, &read_row, &sc_bound, &score_add, &row_leaves, &row_state,
+                        &big_idx, &big_cnt, &big_off, &big_dense, &big_keys, &vsteps2})
          b->release();
       for (auto &e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
       for (hipEvent_t *e : {&ev_seen, &ev_sync, &ev_up}) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
@@ -78,6 +81,7 @@ struct gpumap_batch {
    }
 };
 constexpr int CNT_WORDS = 16;       // [0] cursor [1] hits [2] n_ext [3] error [4..8] stats of k_search (SearchArgs::stats)
+constexpr size_t HOST_CNT_BYTES = 2048;   // the counters as read back: CNT_WORDS + 64 + 64 words, the located total, the count of big candidates
 constexpr size_t H_SMALL_BYTES = 1 << 17;      // lengths seen | phase tables of up to 256 read lengths | counters
 
 // ------------------------------------------------------------------------------------------------
@@ -380,7 +384,7 @@ extern "C" int gpumap_set_option(gpumap_ctx *ctx, const char *name, int64_t valu
    else if (!strcmp(name, "compact_results")) ctx->compact_results = value != 0;
    else if (!strcmp(name, "hit_list_guess")) { GM_FAIL_IF(value < 0, "hit_list_guess out of range."); ctx->hit_guess = value; }
    else if (!strcmp(name, "jump_bytes")) { GM_FAIL_IF(value < 0, "jump_bytes out of range."); ctx->jump_budget = value; HIP_TRY(hipSetDevice(ctx->device)); GM_FAIL_IF(gm_ctx_build_jump(ctx, -1) != 0, "cannot build the jump table."); }
-   else if (!strcmp(name, "verify")) { GM_FAIL_IF(value < -1 || value > 2, "verify out of range."); ctx->verify = (int)value; }
+   else if (!strcmp(name, "verify")) { GM_FAIL_IF(value < -1 || value > 4 || value == 3, "verify out of range (-1, 0, 1, 2, 4)."); ctx->verify = (int)value; }
    else if (!strcmp(name, "jump_k")) { HIP_TRY(hipSetDevice(ctx->device)); GM_FAIL_IF(gm_ctx_build_jump(ctx, (int)value) != 0, "cannot build the jump table."); }
    else if (!strcmp(name, "spill_nodes")) { GM_FAIL_IF(value < 0 || value > (1 << 22), "spill_nodes out of range."); ctx->spill_cap = value ? ((value + SPILL_CHUNK - 1) / SPILL_CHUNK) * SPILL_CHUNK : 16384; }   // (batches size their spill regions at their next run)
    else GM_FAIL("unknown option.");
@@ -558,7 +562,7 @@ extern "C" gpumap_batch *gpumap_batch_new(gpumap_ctx *ctx)
    HIP_TRY(hipEventCreateWithFlags(&b->ev_seen, hipEventDisableTiming));
    for (auto &e : b->ev) HIP_TRY(hipEventCreate(&e));
    HIP_TRY(b->seen.ensure(SEEN_BYTES));
-   HIP_TRY(b->counters.ensure(8 * (CNT_WORDS + 64 + 1)));      // counters + 64 partial sums of k_verify + the count of long intervals (k_place)
+   HIP_TRY(b->counters.ensure(8 * (CNT_WORDS + 128 + 2)));     // counters + 64 partial sums of k_verify + 64 of k_verify_group + the count of long intervals (k_place)
    return b;
 failure_return:
    gpumap_batch_free(b);
@@ -772,7 +776,7 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
       const int64_t R = b->n_reads;
       const bool compact = (result_flags & GM_RESULT_COMPACT) != 0 && !want_intervals;
       b->tau = tau; b->ran = false; b->n_hits = b->n_locs = b->n_ext = 0; b->have_intervals = false;
-      b->sorted_keys = nullptr; b->compact = compact;
+      b->sorted_keys = nullptr; b->compact = compact; b->n_big = 0;
       // ---- K4 (a staged batch): letters -> codes -> bit planes, inside the timed region
       HIP_TRY(hipEventRecord(b->ev[5], st));
       if (!b->encoded) GM_FAIL_IF(batch_encode(ctx, b) != 0, "cannot encode the batch.");
@@ -836,7 +840,7 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
       if (phases.empty()) { phases.assign(MAX_PHASES, 0); phase_rec.assign(2 * MAX_PHASES, 0); phase_lo.assign(MAX_PHASES, 0); }
       if (row_len.empty()) row_len.push_back(0);
       {
-         SmallStage ss{b->h_small + 512, H_SMALL_BYTES - 512 - 1024 - 1024};                               // (the first bytes hold the lengths seen)
+         SmallStage ss{b->h_small + 512, H_SMALL_BYTES - 512 - HOST_CNT_BYTES - 1024};                               // (the first bytes hold the lengths seen)
          const uint16_t *h_len_row = ss.put(len_row);
          const uint32_t *h_phases = ss.put(phases), *h_rec = ss.put(phase_rec);
          const uint8_t *h_lo = ss.put(phase_lo);
@@ -855,7 +859,7 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
       }
       if (sc) {
          if (row_leaves.empty()) { row_leaves.push_back(0); row_state.push_back(1); }
-         SmallStage s2{b->h_small + 512 + (H_SMALL_BYTES - 512 - 1024) - 1024, 1024};      // (the last KiB of the staging block: 2 x 256 bytes)
+         SmallStage s2{b->h_small + H_SMALL_BYTES - HOST_CNT_BYTES - 1024, 1024};      // (the KiB before the counters: 2 x 256 bytes)
          const uint8_t *h_leaves = s2.put(row_leaves), *h_state = s2.put(row_state);
          GM_FAIL_IF(!h_leaves || !h_state, "row tables do not fit the staging block.");
          HIP_TRY(b->row_leaves.ensure(row_leaves.size()));
@@ -896,14 +900,16 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
       const int64_t n_waves = (int64_t)n_wg * WG_WAVES;
       HIP_TRY(b->spill.ensure((size_t)n_waves * (size_t)ctx->spill_cap * sizeof(Node)));
       unsigned long long *cnt = b->counters.as<unsigned long long>();   // [0] cursor [1] hits [2] n_ext [3] error
-      unsigned long long *host_cnt = reinterpret_cast<unsigned long long *>(b->h_small + H_SMALL_BYTES - 1024);   // 8 + 64 words, page-locked
-      constexpr size_t CNT_BYTES = 8 * (CNT_WORDS + 64);
+      unsigned long long *host_cnt = reinterpret_cast<unsigned long long *>(b->h_small + H_SMALL_BYTES - HOST_CNT_BYTES);   // page-locked
+      constexpr size_t CNT_BYTES = 8 * (CNT_WORDS + 128);
       memset(host_cnt, 0, CNT_BYTES);
       // interval output needs the final interval of every hit: no short cut through the text then
-      // 0: every step on the Occ table; 1: nodes of one suffix are finished on the text; 2: also nodes of two.
-      // -1 (default): 2 for texts of 2^31 symbols and more, else 1 (measured: pairs pay where most k-mers of
-      // the jump table's length occur more than once; +8 % at GRCh38 size, -13 % at chr21 size)
-      const int verify_mode = ctx->verify >= 0 ? ctx->verify : (ctx->ix.n >= ((int64_t)1 << 31) ? 2 : 1);
+      // 0: every step on the Occ table; 1: nodes of one suffix are finished on the text; 2: also nodes of two; 4: also
+      // nodes of three and four whose interval has survived a step unchanged (k_verify_group).
+      // -1 (default): 4 for texts of 2^31 symbols and more, else 1 (measured: pairs and groups pay where most k-mers
+      // of the jump table's length occur more than once; at GRCh38 size 22.6 -> 21.0 ms per batch with pairs,
+      // 19.1 -> 18.0 with groups; pairs cost 13 % at chr21 size)
+      const int verify_mode = ctx->verify >= 0 ? ctx->verify : (ctx->ix.n >= ((int64_t)1 << 31) ? 4 : 1);
       const int use_verify = (verify_mode && ctx->d_text != nullptr && ctx->d_text4 != nullptr && !want_intervals && !sc) ? verify_mode : 0;
       // first guess of the list's length (a batch that is run or refilled again keeps the longer list): with
       // k_verify every seed can leave a candidate, plus what repeats add (5.5 entries per read at GRCh38
@@ -927,6 +933,7 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
          A.spill = b->spill.as<Node>(); A.spill_cap = (uint32_t)ctx->spill_cap; A.error = (int *)(cnt + 3); A.stats = cnt + 4;
          A.jump = (const uint4 *)ctx->d_jump; A.jump_k = ctx->jump_k;
          A.verify = use_verify;
+         A.verify_stable = 1;
          A.read_row = sc ? b->read_row.as<const uint16_t>() : nullptr;
          A.sc_bound = sc ? b->sc_bound.as<const int64_t>() : nullptr;
          A.row_leaves = sc ? b->row_leaves.as<const uint8_t>() : nullptr;
@@ -969,10 +976,19 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
          V.direct = b->direct.as<unsigned long long>(); V.sizes = b->hit_sizes.as<int64_t>();
          V.key_shift = pos_bits + 4;
          const int vbd = 256;
-         const bool pairs = use_verify == 2;                             // two lanes per entry
+         const bool pairs = use_verify >= 2;                             // two lanes per entry
+         const bool groups = use_verify == 4;                            // entries of three and four suffixes go to k_verify_group
          const dim3 vgrid((unsigned)cdiv((pairs ? 2 : 1) * V.n_list, vbd));
          HIP_TRY(b->vsteps.ensure(8 * (size_t)vgrid.x));
          V.n_ext = b->vsteps.as<unsigned long long>();
+         V.big_idx = nullptr; V.big_cnt = nullptr;
+         if (groups) {
+            HIP_TRY(b->big_idx.ensure(4 * (size_t)BIG_PER_BLOCK * vgrid.x));
+            HIP_TRY(b->big_cnt.ensure(4 * ((size_t)vgrid.x + 1)));
+            HIP_TRY(b->big_off.ensure(4 * ((size_t)vgrid.x + 1)));
+            HIP_TRY(hipMemsetAsync(b->big_cnt.as<uint32_t>() + vgrid.x, 0, 4, st));
+            V.big_idx = b->big_idx.as<uint32_t>(); V.big_cnt = b->big_cnt.as<uint32_t>();
+         }
 #define GM_VERIFY(N) do { if (pairs) hipLaunchKernelGGL((k_verify<N, true>), vgrid, dim3(vbd), 0, st, V); \
                           else hipLaunchKernelGGL((k_verify<N, false>), vgrid, dim3(vbd), 0, st, V); } while (0)
          switch (cdiv(b->maxlen, 64)) {                                 // 64-letter pieces of the longest read
@@ -984,12 +1000,45 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
 #undef GM_VERIFY
          hipLaunchKernelGGL(k_sum_steps, dim3(64), dim3(256), 0, st, b->vsteps.as<const unsigned long long>(), (int64_t)vgrid.x, cnt + CNT_WORDS);
          HIP_TRY(hipGetLastError());
+         uint32_t *h_nbig = reinterpret_cast<uint32_t *>(host_cnt + CNT_WORDS + 129);
+         *h_nbig = 0;
+         if (groups) {
+            size_t tmp = 0;
+            HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, b->big_cnt.as<uint32_t>(), b->big_off.as<uint32_t>(), (int)vgrid.x + 1, st));
+            HIP_TRY(b->cub_tmp.ensure(tmp));
+            HIP_TRY(hipcub::DeviceScan::ExclusiveSum(b->cub_tmp.p, tmp, b->big_cnt.as<uint32_t>(), b->big_off.as<uint32_t>(), (int)vgrid.x + 1, st));
+            HIP_TRY(hipMemcpyAsync(h_nbig, b->big_off.as<uint32_t>() + vgrid.x, 4, hipMemcpyDeviceToHost, st));
+         }
          HIP_TRY(hipMemcpyAsync(host_cnt, cnt, CNT_BYTES, hipMemcpyDeviceToHost, st));
          GM_SYNC(b, st);
-         for (int k = 0; k < 64; k++) {
+         const int64_t n_big = *h_nbig;
+         if (n_big > 0) {
+            constexpr int G = 4;
+            HIP_TRY(b->big_dense.ensure(4 * (size_t)n_big));
+            HIP_TRY(b->big_keys.ensure(8 * (size_t)G * (size_t)n_big));
+            hipLaunchKernelGGL(k_big_compact, vgrid, dim3(BIG_PER_BLOCK), 0, st, b->big_idx.as<const uint32_t>(), b->big_cnt.as<const uint32_t>(),
+                               b->big_off.as<const uint32_t>(), b->big_dense.as<uint32_t>());
+            const dim3 ggrid((unsigned)cdiv(G * n_big, vbd));
+            HIP_TRY(b->vsteps2.ensure(8 * (size_t)ggrid.x));
+#define GM_GROUP(N) hipLaunchKernelGGL((k_verify_group<N, G>), ggrid, dim3(vbd), 0, st, V, b->big_dense.as<const uint32_t>(), n_big, \
+                                       b->big_keys.as<unsigned long long>(), b->vsteps2.as<unsigned long long>())
+            switch (cdiv(b->maxlen, 64)) {
+               case 1:  GM_GROUP(1); break;
+               case 2:  GM_GROUP(2); break;
+               case 3:  GM_GROUP(3); break;
+               default: GM_GROUP(4); break;
+            }
+#undef GM_GROUP
+            hipLaunchKernelGGL(k_sum_steps, dim3(64), dim3(256), 0, st, b->vsteps2.as<const unsigned long long>(), (int64_t)ggrid.x, cnt + CNT_WORDS + 64);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(host_cnt + CNT_WORDS + 64, cnt + CNT_WORDS + 64, 8 * 64, hipMemcpyDeviceToHost, st));
+            GM_SYNC(b, st);
+         }
+         for (int k = 0; k < (n_big > 0 ? 128 : 64); k++) {
             const unsigned long long st_k = host_cnt[CNT_WORDS + k] & 0xffffffffull;
             host_cnt[2] += st_k; verify_steps += st_k; verify_windows += host_cnt[CNT_WORDS + k] >> 32;
          }
+         b->n_big = n_big;
       }
       HIP_TRY(hipEventRecord(b->ev[1], st));
       b->n_hits = (int64_t)host_cnt[1];            // entries of the list, holes included
@@ -999,6 +1048,10 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
       b->stats[4] = (int64_t)verify_steps;
       b->stats[5] = (int64_t)host_cnt[1];
       b->spill_chunks = (int64_t)host_cnt[8];
+#ifdef GM_STEP_HIST
+      fprintf(stderr, "k_search steps by interval size: 2: %llu  3-4: %llu  5-16: %llu  17-256: %llu  >256: %llu  1: %llu\n",
+              host_cnt[9], host_cnt[10], host_cnt[11], host_cnt[12], host_cnt[13], host_cnt[14]);
+#endif
       b->verify_windows = (int64_t)verify_windows;
 
       // ---- K3 locate: slots per entry -> scan -> every entry fills its slots
@@ -1018,7 +1071,7 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
          HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, b->hit_sizes.as<int64_t>(), b->hit_off.as<int64_t>(), (int)(H + 1), st));
          HIP_TRY(b->cub_tmp.ensure(tmp));
          HIP_TRY(hipcub::DeviceScan::ExclusiveSum(b->cub_tmp.p, tmp, b->hit_sizes.as<int64_t>(), b->hit_off.as<int64_t>(), (int)(H + 1), st));
-         int64_t *h_L = reinterpret_cast<int64_t *>(host_cnt + CNT_WORDS + 64);
+         int64_t *h_L = reinterpret_cast<int64_t *>(host_cnt + CNT_WORDS + 128);
          HIP_TRY(hipMemcpyAsync(h_L, b->hit_off.as<int64_t>() + H, 8, hipMemcpyDeviceToHost, st));
          GM_SYNC(b, st);
          L = *h_L;
@@ -1030,12 +1083,13 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
          HIP_TRY(b->keys_alt.ensure(8 * (size_t)L));
          const unsigned int longer_cap = (unsigned int)(L / PLACE_INLINE + 1);
          HIP_TRY(b->longer.ensure(4 * (size_t)longer_cap));
-         unsigned int *n_longer = (unsigned int *)(cnt + CNT_WORDS + 64);
+         unsigned int *n_longer = (unsigned int *)(cnt + CNT_WORDS + 128);
          HIP_TRY(hipMemsetAsync(n_longer, 0, 8, st));
          hipLaunchKernelGGL(k_place, dim3((unsigned)cdiv(H, 256)), dim3(256), 0, st, ctx->ix, b->hits.as<const Node>(), H,
                             verified ? b->direct.as<const unsigned long long>() : (const unsigned long long *)nullptr,
                             b->hit_sizes.as<const int64_t>(), b->hit_off.as<const int64_t>(), pos_bits, b->keys.as<unsigned long long>(),
-                            b->longer.as<unsigned int>(), n_longer, longer_cap, sc ? b->score_add.as<const uint8_t>() : (const uint8_t *)nullptr);
+                            b->longer.as<unsigned int>(), n_longer, longer_cap, sc ? b->score_add.as<const uint8_t>() : (const uint8_t *)nullptr,
+                            b->big_keys.as<const unsigned long long>(), 4);
          hipLaunchKernelGGL(k_place_long, dim3((unsigned)(4 * ctx->cu_count)), dim3(256), 0, st, ctx->ix, b->hits.as<const Node>(),
                             b->hit_sizes.as<const int64_t>(), b->hit_off.as<const int64_t>(), pos_bits, b->keys.as<unsigned long long>(),
                             b->longer.as<const unsigned int>(), (const unsigned int *)n_longer,
@@ -1157,7 +1211,8 @@ extern "C" int gpumap_batch_stats_ext(const gpumap_batch *b, int64_t stats[8])
    stats[3] = (int64_t)(b->hits.cap / sizeof(Node));
    stats[4] = b->spill_chunks;
    stats[5] = b->verify_windows;
-   stats[6] = stats[7] = 0;
+   stats[6] = b->n_big;
+   stats[7] = 0;
    return 0;
 failure_return:
    return -1;

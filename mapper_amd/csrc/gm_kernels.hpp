@@ -327,7 +327,8 @@ struct SearchArgs {
                                 // [4] chunks of SPILL_CHUNK nodes that deques moved to their spill regions
    const uint4 *jump;           // jump table (k_build_jump) or nullptr
    int jump_k;
-   int verify;                  // nodes with sz <= verify (0, 1 or 2) leave as candidates for k_verify
+   int verify;                  // nodes with sz <= verify (0, 1, 2 or 4) leave as candidates for k_verify
+   int verify_stable;           // 1: those of more than two suffixes only when the last step left the interval as it was
    uint32_t cursor_chunk;       // reads a wave reserves per atomic on the cursor (a multiple of its refill)
    // k_search<true> (blocksc_trail): per query its row of the phase tables (NO_ROW: not searched) and the bound of the
    // left block's hits (src/blocksearch.c:76), per row its number of leaf phases
@@ -410,6 +411,7 @@ struct VerifyArgs {
    unsigned long long *direct;     // [n_list][2] sort keys of the hits a candidate (one or two suffixes) became, ~0 = none
    int64_t *sizes;                 // [n_list] slots of the entry in the located output: such hits, or the suffixes of an interval
    int key_shift;                  // key = read << key_shift | text position << 4 | score (as k_place)
+   uint32_t *big_idx, *big_cnt;    // per block of k_verify<*, true>: the entries that hold more than two suffixes (nullptr: there are none)
 };
 
 // The query row and the text window of a candidate are read as bit planes (k_pack_planes: 16 bytes per
@@ -459,10 +461,232 @@ __device__ __forceinline__ bool test_bit(const uint64_t (&E)[NCH], int pos)
    return r;
 }
 
+// The walk of ONE suffix of a candidate `nd` (suffix q of its interval) along its place of the text: the masks of
+// the window (E, S, QN; with KEEP also the window's planes, for the comparison with the other suffixes of the entry),
+// the steps of the reference schedule the walk stands for, and the sort key of the hit it ends in (~0: none).
+template <int NCH, bool KEEP>
+__device__ __forceinline__ void verify_replay(const VerifyArgs &A, const Node &nd, int q, uint64_t (&E)[NCH], uint64_t (&S)[NCH],
+                                              uint64_t (&QN)[NCH], uint32_t (&tw)[3][2 * NCH], bool &planes, uint32_t &steps,
+                                              unsigned long long &key, int64_t &p0, uint32_t &read, int &row, int &phase0,
+                                              int &pos0, int &end0, bool &fw0)
+{
+   const int64_t fp = ((int64_t)nd.w[0] | ((int64_t)(nd.w[3] & 0xff) << 32)) + q;
+   int pos = (int)(nd.w[3] >> 24);
+   uint32_t meta = nd.w[5] & ~(1u << META_CAND);
+   read = nd.w[4];
+   row = (int)(nd.w[7] >> 24);
+   const int m = A.row_len[row];
+   int phase = (int)(meta & 63);
+   bool fw = (meta >> META_FW) & 1, dash = (meta >> META_DASH) & 1;
+   int end = (meta >> META_END) & 255, tau = (meta >> META_TAU) & 7, diff = (meta >> META_DIFF) & 7;
+   int score = (meta >> META_SCORE) & 7, sref = (meta >> META_SREF) & 7;
+   phase0 = phase; pos0 = pos; end0 = end; fw0 = fw;
+   const int lo = fw ? A.phase_lo[row * MAX_PHASES + phase] : pos + 1;      // lowest query position matched so far
+   p0 = sa_entry(A.ix.sa, A.ix.sar_bits, fp) - lo;                            // text position of query position 0
+   const int nq = (m + 31) >> 5;                                            // 32-letter words of the query row
+   // the window inside the text (the planes have 512 symbols of padding: whole loads can be made)
+   bool fast = p0 >= 0 && p0 + m <= A.ix.n;
+   if (fast) {
+      constexpr int NW = 2 * NCH;                 // 32-letter words of the masks
+      constexpr int NT = (3 * (NW + 1) + 3) / 4;  // 16-byte loads of the window: NW + 1 runs of 12 bytes
+      constexpr int NQ = (3 * NW + 3) / 4;        // 16-byte loads of the query row
+      const uint4 *q16 = reinterpret_cast<const uint4 *>(A.reads4 + (size_t)read * (size_t)(3 * (A.stride >> 3)));
+      const u4x *t16 = reinterpret_cast<const u4x *>(A.text4 + 12 * (p0 >> 5));      // (aligned to 4 bytes)
+      const uint32_t bs = (uint32_t)p0 & 31;      // bit offset of the window in its first words
+      uint32_t T[4 * NT], Q[4 * NQ];
+#pragma unroll
+      for (int k = 0; k < NT; k++) {
+         const u4x v = t16[k];
+         T[4 * k] = v.x; T[4 * k + 1] = v.y; T[4 * k + 2] = v.z; T[4 * k + 3] = v.w;
+      }
+#pragma unroll
+      for (int k = 0; k < NQ; k++) {
+         const uint4 v = q16[k];
+         Q[4 * k] = v.x; Q[4 * k + 1] = v.y; Q[4 * k + 2] = v.z; Q[4 * k + 3] = v.w;
+      }
+      uint32_t qw[3][NW];
+#pragma unroll
+      for (int p = 0; p < 3; p++)
+#pragma unroll
+         for (int w = 0; w < NW; w++) {
+            tw[p][w] = __builtin_amdgcn_alignbit(T[3 * (w + 1) + p], T[3 * w + p], bs);
+            qw[p][w] = Q[3 * w + p];
+         }
+      uint32_t sepacc = 0, Ew[NW];
+#pragma unroll
+      for (int w = 0; w < NW; w++) {
+         // plane 2 is "not a base": a text N against a base costs one, a query N (and what lies behind the read) is free
+         Ew[w] = ((tw[0][w] ^ qw[0][w]) | (tw[1][w] ^ qw[1][w]) | (tw[2][w] ^ qw[2][w])) & ~qw[2][w];
+         if (w < nq) sepacc |= tw[2][w] & tw[0][w];                                 // code 5: a separator
+      }
+#pragma unroll
+      for (int c = 0; c < NCH; c++) {
+         E[c] = (uint64_t)Ew[2 * c] | ((uint64_t)Ew[2 * c + 1] << 32);
+         QN[c] = (uint64_t)qw[2][2 * c] | ((uint64_t)qw[2][2 * c + 1] << 32);
+      }
+      if (sepacc) fast = false;                          // a separator in (or just behind) the window
+      planes = KEEP && fast;
+   }
+   if (!fast) {
+      // a window over an end of the text or over a separator: letter by letter, separators outside the text
+#pragma unroll
+      for (int c = 0; c < NCH; c++) { E[c] = 0; S[c] = 0; QN[c] = 0; }
+      if (KEEP) {
+#pragma unroll
+         for (int p = 0; p < 3; p++)
+#pragma unroll
+            for (int w = 0; w < 2 * NCH; w++) tw[p][w] = 0;
+      }
+      for (int k = 0; k < m; k++) {
+         const int64_t tp = p0 + k;
+         const int t = (tp < 0 || tp >= A.ix.n) ? SYMS : A.text[tp];
+         if (KEEP) {                        // the window's planes, as the fast path keeps them
+#pragma unroll
+            for (int w = 0; w < 2 * NCH; w++)
+               if ((k >> 5) == w) {
+#pragma unroll
+                  for (int p = 0; p < 3; p++) tw[p][w] |= (uint32_t)((t >> p) & 1) << (k & 31);
+               }
+         }
+         const int qc = A.reads[(size_t)read * A.stride + k];
+         const uint64_t bit = 1ull << (k & 63);
+#pragma unroll
+         for (int c = 0; c < NCH; c++) {
+            if ((k >> 6) == c) {
+               if (t == SYMS) S[c] |= bit;
+               if (t == SYMS || (qc != UNKNOWN && t != qc)) E[c] |= bit;     // text N against a base costs one; query N is free
+               if (qc == UNKNOWN) QN[c] |= bit;
+            }
+         }
+      }
+      planes = KEEP;
+   }
+   bool alive = true, final = false;
+   while (alive && !final) {
+      // one phase: positions pos .. end in the phase's direction
+      for (;;) {
+         const int a = fw ? pos : end, b = fw ? end : pos;
+         const int e = first_event<NCH>(E, a, b, fw);
+         if (e < 0) {                                 // plain matches up to the end of the phase
+            steps += (uint32_t)(b - a + 1);
+            pos = end;
+            if (!dash && score - sref < diff) alive = false;          // the rule of the phase's last position
+            break;
+         }
+         // plain matches up to the first letter where something happens, then that letter by the rules
+         steps += (uint32_t)(fw ? e - pos : pos - e) + 1;
+         pos = e;
+         if (test_bit<NCH>(S, e)) { alive = false; break; }           // separator: no child at all
+         if (dash) { alive = false; break; }
+         const int s = score + 1;
+         if (s > tau) { alive = false; break; }
+         if (s == tau) { if (s - sref < diff) { alive = false; break; } dash = true; }
+         else if (pos == end && s - sref < diff) { alive = false; break; }
+         score = s;
+         if (pos == end) break;
+         pos += fw ? 1 : -1;
+      }
+      if (!alive) break;
+      const uint2 rec = A.phase_rec[row * MAX_PHASES + phase];
+      if (rec.y >> 8) { final = true; break; }
+      phase = (int)(rec.x & 63);
+      fw = (rec.x >> META_FW) & 1; dash = (rec.x >> META_DASH) & 1;
+      end = (rec.x >> META_END) & 255; tau = (rec.x >> META_TAU) & 7; diff = (rec.x >> META_DIFF) & 7;
+      sref = score;
+      pos = (int)(rec.y & 255);
+   }
+   // a hit: the text position of the read's first letter, one suffix; or nothing
+   if (final) key = ((unsigned long long)read << A.key_shift) | ((unsigned long long)p0 << 4) | (unsigned long long)score;
+}
+
+// Steps two walks of one entry have in common: the positions of the walk (in the order of the phases, from the
+// node's state) up to and including the first one at which the two places of the text differ (one bwt_query_all
+// there serves both).  E / Eo: the two walks' mismatch masks, TD: where their windows differ (planes_both), else
+// the letters are compared on the byte text.  The caller caps the result by the lengths of the two walks.
+template <int NCH>
+__device__ __forceinline__ uint32_t verify_walked(const VerifyArgs &A, const uint64_t (&E)[NCH], const uint64_t (&Eo)[NCH],
+                                                  const uint64_t (&QN)[NCH], const uint64_t (&TD)[NCH], bool planes_both,
+                                                  int64_t p0, int64_t p0_o, int row, int phase0, int pos0, int end0, bool fw0)
+{
+   uint64_t M[NCH], Dx[NCH];
+#pragma unroll
+   for (int c = 0; c < NCH; c++) { M[c] = E[c] | Eo[c] | QN[c]; Dx[c] = E[c] ^ Eo[c]; }
+   int phase = phase0, pos = pos0, end = end0;
+   bool fw = fw0, parted = false;
+   uint32_t walked = 0;
+   for (;;) {
+      for (;;) {
+         const int a = fw ? pos : end, b = fw ? end : pos;
+         const int e = first_event<NCH>(M, a, b, fw);
+         if (e < 0) { walked += (uint32_t)(b - a + 1); break; }
+         walked += (uint32_t)(fw ? e - pos : pos - e) + 1;
+         bool differ = test_bit<NCH>(Dx, e);
+         if (planes_both) differ = test_bit<NCH>(TD, e);
+         else if (!differ) {
+            const int64_t ta = p0 + e, tb = p0_o + e;
+            const int la = (ta < 0 || ta >= A.ix.n) ? SYMS : A.text[ta], lb = (tb < 0 || tb >= A.ix.n) ? SYMS : A.text[tb];
+            differ = la != lb;
+         }
+         if (differ) { parted = true; break; }
+         if (e == end) break;
+         pos = e + (fw ? 1 : -1);
+      }
+      if (parted) break;
+      const uint2 rec = A.phase_rec[row * MAX_PHASES + phase];
+      if (rec.y >> 8) break;
+      phase = (int)(rec.x & 63);
+      fw = (rec.x >> META_FW) & 1;
+      end = (rec.x >> META_END) & 255;
+      pos = (int)(rec.y & 255);
+   }
+   return walked;
+}
+
+// The same from the mask of the positions where the two windows differ (both lanes hold their window's planes):
+// the first such position in the order of the walk, no stop at the positions where only the query differs.
+template <int NCH>
+__device__ __forceinline__ uint32_t verify_walked_td(const VerifyArgs &A, const uint64_t (&TD)[NCH], int row, int phase0, int pos0,
+                                                     int end0, bool fw0)
+{
+   int phase = phase0, pos = pos0, end = end0;
+   bool fw = fw0;
+   uint32_t walked = 0;
+   for (;;) {
+      const int a = fw ? pos : end, b = fw ? end : pos;
+      const int e = first_event<NCH>(TD, a, b, fw);
+      if (e >= 0) return walked + (uint32_t)(fw ? e - pos : pos - e) + 1;
+      walked += (uint32_t)(b - a + 1);
+      const uint2 rec = A.phase_rec[row * MAX_PHASES + phase];
+      if (rec.y >> 8) return walked;
+      phase = (int)(rec.x & 63);
+      fw = (rec.x >> META_FW) & 1;
+      end = (rec.x >> META_END) & 255;
+      pos = (int)(rec.y & 255);
+   }
+}
+
+// Per block: steps in the low half, windows in the high half (k_sum_steps adds the words up: the halves of its 64
+// sums stay below 2^32 for launches of up to 2^38 steps).  Ends with a workgroup barrier.
+__device__ __forceinline__ void verify_block_sums(uint32_t steps, bool mine, unsigned long long *out)
+{
+   for (int o = 32; o > 0; o >>= 1) steps += (uint32_t)__shfl_xor((int)steps, o);
+   const uint32_t windows = (uint32_t)__popcll(__ballot(mine));          // suffixes this wave replayed
+   __shared__ uint32_t s_steps[4], s_windows[4];
+   if ((threadIdx.x & 63) == 0) { s_steps[threadIdx.x >> 6] = steps; s_windows[threadIdx.x >> 6] = windows; }
+   __syncthreads();
+   if (threadIdx.x == 0) out[blockIdx.x] = ((unsigned long long)s_steps[0] + s_steps[1] + s_steps[2] + s_steps[3]) |
+                                           (((unsigned long long)s_windows[0] + s_windows[1] + s_windows[2] + s_windows[3]) << 32);
+}
+
+constexpr unsigned long long DIRECT_BIG = ~0ull - 1ull;    // direct[2i]: the entry's keys are in big_keys (k_verify_group), direct[2i+1] = its group
+constexpr int BIG_PER_BLOCK = 128;                         // entries of a k_verify<*, true> block (two lanes each)
+
 // PAIRS: two lanes per entry of the list.  An entry that is a candidate then holds one or two suffixes;
 // lane q of the pair replays suffix q.  The two walks of a pair share the nodes of the reference's search
 // tree as long as the two places of the text spell the same letters along the walk: those steps are
 // counted once.  Without PAIRS every candidate holds one suffix and an entry has one lane.
+// Candidates of more than two suffixes (option verify = 4: up to four) are left to k_verify_group: this kernel
+// only lists them, per block (A.big_idx, A.big_cnt; no atomics).
 template <int NCH, bool PAIRS>
 __global__ void __launch_bounds__(256) k_verify(VerifyArgs A)
 {
@@ -472,10 +696,10 @@ __global__ void __launch_bounds__(256) k_verify(VerifyArgs A)
    const int q = PAIRS ? (int)(th & 1) : 0;
    uint32_t steps = 0;                 // this walk's steps (0 for a lane without a suffix)
    unsigned long long key = ~0ull;
-   bool cand = false, pair = false;
+   bool cand = false, pair = false, big = false;
    int64_t p0 = 0;
    uint32_t read = 0;
-   int row = 0, m = 0;
+   int row = 0;
    int phase0 = 0, pos0 = 0, end0 = 0;
    bool fw0 = false;
    uint64_t E[NCH], S[NCH], QN[NCH];
@@ -501,122 +725,12 @@ __global__ void __launch_bounds__(256) k_verify(VerifyArgs A)
    if (cand) {
       Node nd = A.list[i];
       pair = PAIRS && nd.w[2] == 2;
-      mine = q == 0 || pair;
+      big = PAIRS && nd.w[2] > 2;
+      mine = !big && (q == 0 || pair);
    }
    if (mine) {
       Node nd = A.list[i];
-      const int64_t fp = ((int64_t)nd.w[0] | ((int64_t)(nd.w[3] & 0xff) << 32)) + q;
-      int pos = (int)(nd.w[3] >> 24);
-      uint32_t meta = nd.w[5] & ~(1u << META_CAND);
-      read = nd.w[4];
-      row = (int)(nd.w[7] >> 24);
-      m = A.row_len[row];
-      int phase = (int)(meta & 63);
-      bool fw = (meta >> META_FW) & 1, dash = (meta >> META_DASH) & 1;
-      int end = (meta >> META_END) & 255, tau = (meta >> META_TAU) & 7, diff = (meta >> META_DIFF) & 7;
-      int score = (meta >> META_SCORE) & 7, sref = (meta >> META_SREF) & 7;
-      phase0 = phase; pos0 = pos; end0 = end; fw0 = fw;
-      const int lo = fw ? A.phase_lo[row * MAX_PHASES + phase] : pos + 1;      // lowest query position matched so far
-      p0 = sa_entry(A.ix.sa, A.ix.sar_bits, fp) - lo;                            // text position of query position 0
-      const int nq = (m + 31) >> 5;                                            // 32-letter words of the query row
-      // the window inside the text (the planes have 512 symbols of padding: whole loads can be made)
-      bool fast = p0 >= 0 && p0 + m <= A.ix.n;
-      if (fast) {
-         constexpr int NW = 2 * NCH;                 // 32-letter words of the masks
-         constexpr int NT = (3 * (NW + 1) + 3) / 4;  // 16-byte loads of the window: NW + 1 runs of 12 bytes
-         constexpr int NQ = (3 * NW + 3) / 4;        // 16-byte loads of the query row
-         const uint4 *q16 = reinterpret_cast<const uint4 *>(A.reads4 + (size_t)read * (size_t)(3 * (A.stride >> 3)));
-         const u4x *t16 = reinterpret_cast<const u4x *>(A.text4 + 12 * (p0 >> 5));      // (aligned to 4 bytes)
-         const uint32_t bs = (uint32_t)p0 & 31;      // bit offset of the window in its first words
-         uint32_t T[4 * NT], Q[4 * NQ];
-#pragma unroll
-         for (int k = 0; k < NT; k++) {
-            const u4x v = t16[k];
-            T[4 * k] = v.x; T[4 * k + 1] = v.y; T[4 * k + 2] = v.z; T[4 * k + 3] = v.w;
-         }
-#pragma unroll
-         for (int k = 0; k < NQ; k++) {
-            const uint4 v = q16[k];
-            Q[4 * k] = v.x; Q[4 * k + 1] = v.y; Q[4 * k + 2] = v.z; Q[4 * k + 3] = v.w;
-         }
-         uint32_t qw[3][NW];
-#pragma unroll
-         for (int p = 0; p < 3; p++)
-#pragma unroll
-            for (int w = 0; w < NW; w++) {
-               tw[p][w] = __builtin_amdgcn_alignbit(T[3 * (w + 1) + p], T[3 * w + p], bs);
-               qw[p][w] = Q[3 * w + p];
-            }
-         uint32_t sepacc = 0, Ew[NW];
-#pragma unroll
-         for (int w = 0; w < NW; w++) {
-            // plane 2 is "not a base": a text N against a base costs one, a query N (and what lies behind the read) is free
-            Ew[w] = ((tw[0][w] ^ qw[0][w]) | (tw[1][w] ^ qw[1][w]) | (tw[2][w] ^ qw[2][w])) & ~qw[2][w];
-            if (w < nq) sepacc |= tw[2][w] & tw[0][w];                                 // code 5: a separator
-         }
-#pragma unroll
-         for (int c = 0; c < NCH; c++) {
-            E[c] = (uint64_t)Ew[2 * c] | ((uint64_t)Ew[2 * c + 1] << 32);
-            QN[c] = (uint64_t)qw[2][2 * c] | ((uint64_t)qw[2][2 * c + 1] << 32);
-         }
-         if (sepacc) fast = false;                          // a separator in (or just behind) the window
-         planes = KEEP_PLANES && fast;
-      }
-      if (!fast) {
-         // a window over an end of the text or over a separator: letter by letter, separators outside the text
-#pragma unroll
-         for (int c = 0; c < NCH; c++) { E[c] = 0; S[c] = 0; QN[c] = 0; }
-         for (int k = 0; k < m; k++) {
-            const int64_t tp = p0 + k;
-            const int t = (tp < 0 || tp >= A.ix.n) ? SYMS : A.text[tp];
-            const int qc = A.reads[(size_t)read * A.stride + k];
-            const uint64_t bit = 1ull << (k & 63);
-#pragma unroll
-            for (int c = 0; c < NCH; c++) {
-               if ((k >> 6) == c) {
-                  if (t == SYMS) S[c] |= bit;
-                  if (t == SYMS || (qc != UNKNOWN && t != qc)) E[c] |= bit;     // text N against a base costs one; query N is free
-                  if (qc == UNKNOWN) QN[c] |= bit;
-               }
-            }
-         }
-      }
-      bool alive = true, final = false;
-      while (alive && !final) {
-         // one phase: positions pos .. end in the phase's direction
-         for (;;) {
-            const int a = fw ? pos : end, b = fw ? end : pos;
-            const int e = first_event<NCH>(E, a, b, fw);
-            if (e < 0) {                                 // plain matches up to the end of the phase
-               steps += (uint32_t)(b - a + 1);
-               pos = end;
-               if (!dash && score - sref < diff) alive = false;          // the rule of the phase's last position
-               break;
-            }
-            // plain matches up to the first letter where something happens, then that letter by the rules
-            steps += (uint32_t)(fw ? e - pos : pos - e) + 1;
-            pos = e;
-            if (test_bit<NCH>(S, e)) { alive = false; break; }           // separator: no child at all
-            if (dash) { alive = false; break; }
-            const int s = score + 1;
-            if (s > tau) { alive = false; break; }
-            if (s == tau) { if (s - sref < diff) { alive = false; break; } dash = true; }
-            else if (pos == end && s - sref < diff) { alive = false; break; }
-            score = s;
-            if (pos == end) break;
-            pos += fw ? 1 : -1;
-         }
-         if (!alive) break;
-         const uint2 rec = A.phase_rec[row * MAX_PHASES + phase];
-         if (rec.y >> 8) { final = true; break; }
-         phase = (int)(rec.x & 63);
-         fw = (rec.x >> META_FW) & 1; dash = (rec.x >> META_DASH) & 1;
-         end = (rec.x >> META_END) & 255; tau = (rec.x >> META_TAU) & 7; diff = (rec.x >> META_DIFF) & 7;
-         sref = score;
-         pos = (int)(rec.y & 255);
-      }
-      // a hit: the text position of the read's first letter, one suffix; or nothing
-      if (final) key = ((unsigned long long)read << A.key_shift) | ((unsigned long long)p0 << 4) | (unsigned long long)score;
+      verify_replay<NCH, KEEP_PLANES>(A, nd, q, E, S, QN, tw, planes, steps, key, p0, read, row, phase0, pos0, end0, fw0);
    }
    // ---- the pair: what the partner found (lanes 2k and 2k+1 of a wave; every lane takes part in the exchange)
    unsigned long long key_o = ~0ull;
@@ -652,56 +766,112 @@ __global__ void __launch_bounds__(256) k_verify(VerifyArgs A)
       for (int c = 0; c < NCH; c++) TD[c] = (uint64_t)dw[2 * c] | ((uint64_t)dw[2 * c + 1] << 32);
    }
    if (pair && q == 1) {
-      // steps the two walks have in common: the positions of the walk up to and including the first one at
-      // which the two places of the text differ (one bwt_query_all there serves both), at most either walk
-      uint64_t M[NCH], Dx[NCH];
-#pragma unroll
-      for (int c = 0; c < NCH; c++) { M[c] = E[c] | Eo[c] | QN[c]; Dx[c] = E[c] ^ Eo[c]; }
-      int phase = phase0, pos = pos0, end = end0;
-      bool fw = fw0, parted = false;
-      uint32_t walked = 0;
-      for (;;) {
-         for (;;) {
-            const int a = fw ? pos : end, b = fw ? end : pos;
-            const int e = first_event<NCH>(M, a, b, fw);
-            if (e < 0) { walked += (uint32_t)(b - a + 1); break; }
-            walked += (uint32_t)(fw ? e - pos : pos - e) + 1;
-            bool differ = test_bit<NCH>(Dx, e);
-            if (planes_both) differ = test_bit<NCH>(TD, e);
-            else if (!differ) {
-               const int64_t ta = p0 + e, tb = p0_o + e;
-               const int la = (ta < 0 || ta >= A.ix.n) ? SYMS : A.text[ta], lb = (tb < 0 || tb >= A.ix.n) ? SYMS : A.text[tb];
-               differ = la != lb;
-            }
-            if (differ) { parted = true; break; }
-            if (e == end) break;
-            pos = e + (fw ? 1 : -1);
-         }
-         if (parted) break;
-         const uint2 rec = A.phase_rec[row * MAX_PHASES + phase];
-         if (rec.y >> 8) break;
-         phase = (int)(rec.x & 63);
-         fw = (rec.x >> META_FW) & 1;
-         end = (rec.x >> META_END) & 255;
-         pos = (int)(rec.y & 255);
-      }
-      shared = min(walked, min(steps, steps_o));
+      const uint32_t wk = planes_both ? verify_walked_td<NCH>(A, TD, row, phase0, pos0, end0, fw0)
+                                      : verify_walked<NCH>(A, E, Eo, QN, TD, false, p0, p0_o, row, phase0, pos0, end0, fw0);
+      shared = min(wk, min(steps, steps_o));
    }
-   if (cand && q == 0) {
+   if (cand && !big && q == 0) {
       const bool f0 = key != ~0ull, f1 = key_o != ~0ull;
       *reinterpret_cast<ulonglong2 *>(A.direct + 2 * i) = make_ulonglong2(f0 ? key : key_o, f0 && f1 ? key_o : ~0ull);
       A.sizes[i] = (f0 ? 1 : 0) + (f1 ? 1 : 0);
    }
    steps -= shared;
-   for (int o = 32; o > 0; o >>= 1) steps += (uint32_t)__shfl_xor((int)steps, o);
-   const uint32_t windows = (uint32_t)__popcll(__ballot(mine));          // suffixes this wave replayed
-   __shared__ uint32_t s_steps[4], s_windows[4];
-   if ((threadIdx.x & 63) == 0) { s_steps[threadIdx.x >> 6] = steps; s_windows[threadIdx.x >> 6] = windows; }
-   __syncthreads();
-   // per block: steps in the low half, windows in the high half (k_sum_steps adds the words up: the halves of
-   // its 64 sums stay below 2^32 for launches of up to 2^38 steps)
-   if (threadIdx.x == 0) A.n_ext[blockIdx.x] = ((unsigned long long)s_steps[0] + s_steps[1] + s_steps[2] + s_steps[3]) |
-                                               (((unsigned long long)s_windows[0] + s_windows[1] + s_windows[2] + s_windows[3]) << 32);
+   __shared__ uint32_t s_big[4];
+   const unsigned long long bigm = __ballot(big && q == 0);
+   if (PAIRS && (threadIdx.x & 63) == 0) s_big[threadIdx.x >> 6] = (uint32_t)__popcll(bigm);
+   verify_block_sums(steps, mine, A.n_ext);         // (barrier inside)
+   if (PAIRS && A.big_idx != nullptr) {
+      const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+      uint32_t off = 0, total = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) { if (k < w) off += s_big[k]; total += s_big[k]; }
+      if (big && q == 0)
+         A.big_idx[(size_t)blockIdx.x * BIG_PER_BLOCK + off + (uint32_t)__popcll(bigm & ((1ull << lane) - 1ull))] = (uint32_t)i;
+      if (threadIdx.x == 0) A.big_cnt[blockIdx.x] = total;
+   }
+}
+
+// The per-block lists of k_verify made one dense list (off = exclusive scan of the blocks' counts).
+__global__ void __launch_bounds__(BIG_PER_BLOCK) k_big_compact(const uint32_t *big_idx, const uint32_t *big_cnt, const uint32_t *big_off,
+                                                              uint32_t *dense)
+{
+   const uint32_t n = big_cnt[blockIdx.x];
+   if (threadIdx.x < n) dense[big_off[blockIdx.x] + threadIdx.x] = big_idx[(size_t)blockIdx.x * BIG_PER_BLOCK + threadIdx.x];
+}
+
+// Candidates of three to G suffixes: G lanes per entry, lane q replays suffix q.  The walks of one entry are paths
+// of the reference's search tree from one node; the bwt_query_all calls they stand for are the nodes of the union
+// of those paths: walk q adds its own steps minus the most it shares with any walk before it (two paths share
+// their nodes up to and including the first position where their texts differ: verify_walked).  Keys go to
+// big_keys[group][q]; the entry's number of hits to sizes[], and direct[2i] = DIRECT_BIG, direct[2i+1] = group tell
+// k_place where they are.
+template <int NCH, int G>
+__global__ void __launch_bounds__(256) k_verify_group(VerifyArgs A, const uint32_t *dense, int64_t n_big, unsigned long long *big_keys,
+                                                      unsigned long long *n_ext_out)
+{
+   const int64_t th = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+   const int64_t g = th / G;
+   const int q = (int)(th % G);
+   const int lane = threadIdx.x & 63, base = lane & ~(G - 1);
+   uint32_t steps = 0;
+   unsigned long long key = ~0ull;
+   int64_t p0 = 0, i = 0;
+   uint32_t read = 0;
+   int row = 0, phase0 = 0, pos0 = 0, end0 = 0, csz = 0;
+   bool fw0 = false, planes = false;
+   uint64_t E[NCH], S[NCH], QN[NCH];
+#pragma unroll
+   for (int c = 0; c < NCH; c++) { E[c] = 0; S[c] = 0; QN[c] = 0; }
+   uint32_t tw[3][2 * NCH];
+#pragma unroll
+   for (int p = 0; p < 3; p++)
+#pragma unroll
+      for (int w = 0; w < 2 * NCH; w++) tw[p][w] = 0;
+   constexpr bool KEEP_PLANES = NCH <= 2;
+   const bool valid = g < n_big;
+   if (valid) { i = dense[g]; csz = (int)A.list[i].w[2]; }
+   const bool mine = valid && q < csz;
+   if (mine) {
+      Node nd = A.list[i];
+      verify_replay<NCH, KEEP_PLANES>(A, nd, q, E, S, QN, tw, planes, steps, key, p0, read, row, phase0, pos0, end0, fw0);
+   }
+   uint32_t best = 0;
+#pragma unroll
+   for (int j = 0; j < G - 1; j++) {              // every lane takes part in the exchanges
+      const int src = base + j;
+      const uint32_t steps_o = (uint32_t)__shfl((int)steps, src);
+      uint32_t wk = 0;
+      if (KEEP_PLANES) {
+         // every walk holds its window's planes (the letter-by-letter path fills them too): where the two windows differ
+         uint32_t dw[2 * NCH];
+#pragma unroll
+         for (int w = 0; w < 2 * NCH; w++) {
+            dw[w] = 0;
+#pragma unroll
+            for (int p = 0; p < 3; p++) dw[w] |= tw[p][w] ^ (uint32_t)__shfl((int)tw[p][w], src);
+         }
+         uint64_t TD[NCH];
+#pragma unroll
+         for (int c = 0; c < NCH; c++) TD[c] = (uint64_t)dw[2 * c] | ((uint64_t)dw[2 * c + 1] << 32);
+         if (mine && q > j) wk = verify_walked_td<NCH>(A, TD, row, phase0, pos0, end0, fw0);
+      } else {
+         uint64_t Eo[NCH], TD[NCH];
+#pragma unroll
+         for (int c = 0; c < NCH; c++) { Eo[c] = __shfl(E[c], src); TD[c] = 0; }
+         const int64_t p0_o = __shfl(p0, src);
+         if (mine && q > j) wk = verify_walked<NCH>(A, E, Eo, QN, TD, false, p0, p0_o, row, phase0, pos0, end0, fw0);
+      }
+      if (mine && q > j) best = max(best, min(wk, min(steps, steps_o)));
+   }
+   // the keys of the hits, packed to the front of the group's G slots
+   const unsigned long long foundm = (__ballot(key != ~0ull) >> base) & ((1ull << G) - 1ull);
+   if (valid && key != ~0ull) big_keys[g * G + __popcll(foundm & ((1ull << q) - 1ull))] = key;
+   if (valid && q == 0) {
+      A.sizes[i] = (int64_t)__popcll(foundm);
+      *reinterpret_cast<ulonglong2 *>(A.direct + 2 * i) = make_ulonglong2(DIRECT_BIG, (unsigned long long)g);
+   }
+   steps -= best;
+   verify_block_sums(steps, mine, n_ext_out);
 }
 
 // The steps of a k_verify launch: 64 blocks add up the per-block counts, one sum per block (what the host adds up).
@@ -811,12 +981,24 @@ __global__ void k_hit_sizes(const Node *hits, int64_t n_hits, int64_t *sizes)
 __global__ void __launch_bounds__(256) k_place(IndexDev ix, const Node *hits, int64_t n_hits, const unsigned long long *direct,
                                                const int64_t *sizes, const int64_t *hit_off, int pos_bits,
                                                unsigned long long *keys, unsigned int *longer, unsigned int *n_longer, unsigned int longer_cap,
-                                               const uint8_t *score_add /* per read (blocksc_trail adds the N count, :94-97) or nullptr */)
+                                               const uint8_t *score_add /* per read (blocksc_trail adds the N count, :94-97) or nullptr */,
+                                               const unsigned long long *big_keys, int big_g)
 {
    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
    if (i >= n_hits) return;
    if (direct) {
       const ulonglong2 k = *reinterpret_cast<const ulonglong2 *>(direct + 2 * i);
+      if (k.x == DIRECT_BIG) {                     // an entry of k_verify_group: its hits' keys are the first sizes[i] of its four slots
+         const int64_t off = hit_off[i], cnt = sizes[i];
+         if (cnt == 0) return;
+         const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(big_keys + k.y * 4);
+         const ulonglong2 a = src[0], b = src[1];
+         keys[off] = a.x;
+         if (cnt > 1) keys[off + 1] = a.y;
+         if (cnt > 2) keys[off + 2] = b.x;
+         if (cnt > 3) keys[off + 3] = b.y;
+         return;
+      }
       if (k.x != ~0ull) {
          const int64_t off = hit_off[i];
          keys[off] = k.x;

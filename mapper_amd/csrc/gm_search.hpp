@@ -188,6 +188,9 @@ __global__ void __launch_bounds__(WG_THREADS) k_search(SearchArgs A)
    int qword_at = -1;           // pos >> 2 of the cached word, -1 = none
    unsigned long long ext_count = 0;
    uint32_t jump_steps = 0;     // extension steps of this lane's seeds that the jump table stood in for
+#ifdef GM_STEP_HIST
+   unsigned long long h_cnt[6] = {0, 0, 0, 0, 0, 0};
+#endif
 
    for (;;) {
       // ------------------------------------------------------------ hand nodes to idle lanes
@@ -291,6 +294,17 @@ __global__ void __launch_bounds__(WG_THREADS) k_search(SearchArgs A)
          if (!reads_left && wq.spill_top == 0 && wq.top == wq.bot) break;
          continue;
       }
+#ifdef GM_STEP_HIST
+      {  // diagnostic build: extension steps by the size of the interval they extend
+         const bool fresh = have && ((meta >> META_FIRST) & 7) == 0;
+         h_cnt[0] += __popcll(__ballot(fresh && sz == 2));
+         h_cnt[1] += __popcll(__ballot(fresh && sz >= 3 && sz <= 4));
+         h_cnt[2] += __popcll(__ballot(fresh && sz >= 5 && sz <= 16));
+         h_cnt[3] += __popcll(__ballot(fresh && sz >= 17 && sz <= 256));
+         h_cnt[4] += __popcll(__ballot(fresh && sz > 256));
+         h_cnt[5] += __popcll(__ballot(fresh && sz == 1));
+      }
+#endif
       const int first = (int)(meta >> META_FIRST) & 7;
       ext_count += (unsigned long long)__popcll(__ballot(have && first == 0));   // a continuation was counted at its first visit
       n_iter++;
@@ -361,7 +375,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_search(SearchArgs A)
          wave_push<QCAP, SPILL_CHUNK>(wq, cont, out, lane);
          n_cont += (unsigned long long)__popcll(__ballot(cont));
       }
-      bool emit = false;
+      bool emit = false, stable = false;
       if (cand != 0) {
          const int nt = __ffs((int)cand) - 1;
          const int js = fw ? complement(nt) : nt;
@@ -369,7 +383,9 @@ __global__ void __launch_bounds__(WG_THREADS) k_search(SearchArgs A)
          const int64_t r3 = other + (sz - tot), r2 = r3 + szn[3], r1 = r2 + szn[2], r0 = r1 + szn[1], r4 = r0 + szn[0];
          const int64_t fpn = (int64_t)(s_cb[sb0 * SYMS + js] + sel5(rel0, js));
          const int64_t rpn = sel5v(r0, r1, r2, r3, r4, js);
+         const int64_t sz_parent = sz;
          sz = sel5(szn, js);
+         stable = sz == sz_parent;
          fp = fw ? rpn : fpn;
          rp = fw ? fpn : rpn;
          uint32_t meta_n;
@@ -402,7 +418,10 @@ __global__ void __launch_bounds__(WG_THREADS) k_search(SearchArgs A)
       // A node whose interval has shrunk to one suffix (A.verify = 2: to one or two) leaves the search: k_verify
       // finishes it against the text (a suffix-array entry and a window of the text per suffix instead of
       // Occ lines per letter).
-      const bool toverify = A.verify && have && !emit && sz <= A.verify;
+      // (three and four suffixes only once the interval has survived a step unchanged: what a coincidence of the
+      // seed's letters adds to an interval is gone after a letter or two and is cheaper to shed on the Occ table
+      // than to replay; copies of a repeat stay)
+      const bool toverify = A.verify && have && !emit && (sz <= 2 ? sz <= A.verify : (sz <= A.verify && (stable || !A.verify_stable)));
       if (__any(emit || toverify)) {
          Node out;
          out.w[0] = (uint32_t)fp; out.w[1] = (uint32_t)rp; out.w[2] = (uint32_t)sz;
@@ -416,6 +435,9 @@ __global__ void __launch_bounds__(WG_THREADS) k_search(SearchArgs A)
    }
    hit_finish(A, hr, lane);
    if (lane == 0 && wq.n_spilled) atomicAdd(A.stats + 4, (unsigned long long)wq.n_spilled);
+#ifdef GM_STEP_HIST
+   if (lane == 0) for (int k = 0; k < 6; k++) atomicAdd(A.stats + 5 + k, h_cnt[k]);
+#endif
    for (int o = 32; o > 0; o >>= 1) jump_steps += (uint32_t)__shfl_xor((int)jump_steps, o);
    ext_count += jump_steps;
    if (lane == 0 && ext_count) {
