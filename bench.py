@@ -467,7 +467,7 @@ def pmc_traffic(workload):
         path = os.path.join(ROOT, "profiles", "%s_%s_profile_summary.json" % (rnd, workload))
         try:
             pm = json.load(open(path))["pmc_per_launch"]
-            k = pm.get("gm::k_search") or next(iter(pm.values()))
+            k = next(v for name, v in pm.items() if "gm::k_search" in name)
             req = k.get("TCC_EA0_RDREQ_sum", {}).get("avg")
             return (k["FETCH_SIZE"]["avg"] + k["WRITE_SIZE"]["avg"]) * 1024.0, os.path.relpath(path, ROOT), req
         except Exception:

@@ -139,6 +139,11 @@ int gpumap_occ_all(gpumap_ctx *ctx, int64_t n, const int64_t *ptr, int64_t *occ)
 ** extension by symbol j at `end` (GPUMAP_QUERY_PREFIX / _SUFFIX); depth is the caller's dp + 1. */
 int gpumap_query_all(gpumap_ctx *ctx, int end, int64_t n, const int64_t *fp, const int64_t *rp,
                      const int64_t *sz, int64_t *out);
+/* bwt_prefix_all (src/index_bwt.c:390-446) for n intervals: out[i][j] = {fp, sz} of the one-letter prefix
+** extension by symbol j, fp = c[j] + occ(fp_i - 1)[j], sz clamped at 0 (:432); the reference leaves rp = -1, so no
+** reverse pointer here either.  An interval whose ranks get_occ_all refuses (fp < 0, fp + sz outside 0..n) gives
+** ten words of -1. */
+int gpumap_prefix_all(gpumap_ctx *ctx, int64_t n, const int64_t *fp, const int64_t *sz, int64_t *out);
 /* gpumap_query_all without any allocation.  No counterpart in the reference: it is for callers that cannot
 ** call hipMalloc (code under HIP graph capture, tight serving loops, harnesses that forbid allocation).
 ** Same arguments and results as gpumap_query_all, at most GPUMAP_NOALLOC_MAX_QUERIES intervals per call

@@ -84,6 +84,7 @@ API = {
     "gpumap_occ_all": (_I, [_P, _I64, _P, _P]),
     "gpumap_query_all": (_I, [_P, _I, _I64, _P, _P, _P, _P]),
     "gpumap_query_all_noalloc": (_I, [_P, _I, _I64, _P, _P, _P, _P]),
+    "gpumap_prefix_all": (_I, [_P, _I64, _P, _P, _P]),
     "gpumap_sar_get": (_I, [_P, _I64, _P, _P]),
     "gpumap_sar_get_range": (_I, [_P, _I64, _I64, _P]),
     "gpumap_encode": (_I, [_P, _P, _P, _I64, _P]),
@@ -513,6 +514,14 @@ class Context:
         out = np.empty((len(fp), 5, 3), dtype=np.int64)
         if lib().gpumap_query_all(self._h, end, len(fp), _ptr(fp), _ptr(rp), _ptr(sz), _ptr(out)) != 0:
             raise GpumapError("gpumap_query_all failed")
+        return out
+
+    def prefix_all(self, fp, sz):
+        """bwt_prefix_all for len(fp) intervals: out[i][j] = (fp, sz) of the prefix extension by symbol j."""
+        fp, sz = (np.ascontiguousarray(x, dtype=np.int64) for x in (fp, sz))
+        out = np.empty((len(fp), 5, 2), dtype=np.int64)
+        if lib().gpumap_prefix_all(self._h, len(fp), _ptr(fp), _ptr(sz), _ptr(out)) != 0:
+            raise GpumapError("gpumap_prefix_all failed")
         return out
 
     def query_all_noalloc(self, end, fp, rp, sz):

@@ -444,6 +444,29 @@ failure_return:
    return -1;
 }
 
+extern "C" int gpumap_prefix_all(gpumap_ctx *ctx, int64_t n, const int64_t *fp, const int64_t *sz, int64_t *out)
+{
+   GM_FAIL_IF(ctx == nullptr, "argument 'ctx' is NULL.");
+   GM_FAIL_IF(n < 0 || (n > 0 && (!fp || !sz || !out)), "invalid arguments.");
+   if (n == 0) return 0;
+   HIP_TRY(hipSetDevice(ctx->device));
+   HIP_TRY(ctx->op_in.ensure(16 * (size_t)n));
+   HIP_TRY(ctx->op_out.ensure(16 * SYMS * (size_t)n));
+   {
+      int64_t *d = ctx->op_in.as<int64_t>();
+      HIP_TRY(hipMemcpyAsync(d, fp, 8 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+      HIP_TRY(hipMemcpyAsync(d + n, sz, 8 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+      hipLaunchKernelGGL(k_prefix_all, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, ctx->stream, ctx->ix, n,
+                         (const int64_t *)d, (const int64_t *)(d + n), ctx->op_out.as<int64_t>());
+   }
+   HIP_TRY(hipGetLastError());
+   HIP_TRY(hipMemcpyAsync(out, ctx->op_out.p, 16 * SYMS * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+   HIP_TRY(hipStreamSynchronize(ctx->stream));
+   return 0;
+failure_return:
+   return -1;
+}
+
 // gpumap_query_all for callers that cannot allocate: the staging of gpumap_query_all (op_in / op_out, grown with
 // hipMalloc) is the static `scratch` array, through the device address looked up at context creation.  No
 // hipMalloc / hipFree here.  Nothing in the scratch has to start at zero: k_query_all writes all 15 words of

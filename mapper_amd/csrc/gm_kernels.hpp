@@ -129,6 +129,27 @@ __global__ void k_query_all(IndexDev ix, int end, int64_t n, const int64_t *fp, 
    }
 }
 
+// bwt_prefix_all for n intervals (src/index_bwt.c:390-446): the forward pointer and the size of the five one-letter
+// prefix extensions, out[i][j] = {c[j] + occ(fp - 1)[j], max(0, occ(fp + sz - 1)[j] - occ(fp - 1)[j])}; no reverse
+// pointer (the reference sets rp = -1).  A rank the reference's get_occ_all refuses (pointer below -1 or beyond the
+// last position) makes the ten words of that interval -1.
+__global__ void k_prefix_all(IndexDev ix, int64_t n, const int64_t *fp, const int64_t *sz, int64_t *out)
+{
+   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+   if (i >= n) return;
+   int64_t a = fp[i], b = a + sz[i];
+   int64_t *o = out + 2 * SYMS * i;
+   if (a < 0 || a > ix.n || b < 0 || b > ix.n) { for (int k = 0; k < 2 * SYMS; k++) o[k] = -1; return; }
+   int64_t occ0[SYMS], occ1[SYMS];
+   rank_abs(ix, a, occ0);
+   rank_abs(ix, b, occ1);
+   for (int j = 0; j < SYMS; j++) {
+      int64_t s = occ1[j] - occ0[j];
+      o[2 * j + 0] = (int64_t)ix.tables[TAB_C + j] + occ0[j];
+      o[2 * j + 1] = s < 0 ? 0 : s;
+   }
+}
+
 // Jump table: entry idx = the state of the exact right-to-left search of one K-mer from the root
 // interval, i.e. what the first K iterations of a leaf phase (seqsearch_bw with tau 0,
 // src/blocksearch.c:138-144, :440-496) compute for the query symbols s_0 (first, rightmost) .. s_{K-1},

@@ -122,7 +122,7 @@ int suffix_sort_impl(const uint8_t *data, int64_t n, int64_t *sa_out, int thread
       std::vector<Grp> merged;
       for (auto &v : next) merged.insert(merged.end(), v.begin(), v.end());
       groups.swap(merged);
-      if (h > 2 * n) break;   // cannot happen for a valid text; guards against a logic error
+      if (h > 2 * n && !groups.empty()) return -1;   // ties left after comparing more than n letters: a logic error, never a partial order handed on
    }
    for (int64_t j = 0; j < n; j++) sa_out[j] = (int64_t)sa[j];
    return 0;

@@ -55,6 +55,37 @@ def test_query_all_matches_oracle(small):
         assert np.array_equal(got, want)
 
 
+def test_prefix_all_matches_oracle(small):
+    """gpumap_prefix_all against the restatement of bwt_prefix_all (src/index_bwt.c:390-446), which
+    tests/test_oracle_golden.py pins to the reference's known answers (test/test_index_bwt.c:187-238): intervals of a
+    backward walk, empty intervals, the whole table, sizes past the interval of any word (clamped at 0 only when
+    negative), and pointers the reference refuses."""
+    base, ctx, orc = small
+    n = orc.txt_len
+    rng = np.random.default_rng(12)
+    fp, sz = [0, 0, n, n - 1, 5], [n, 0, 0, 1, 0]
+    cur = [(0, n)]
+    for depth in range(14):
+        nxt = []
+        for (f, s) in cur:
+            ch = orc.prefix_all(f, s)
+            nxt += [c for c in ch if c[1] > 0 and rng.random() < 0.5]
+        cur = nxt[:300] or cur
+        fp += [c[0] for c in cur]; sz += [c[1] for c in cur]
+    lo = rng.integers(0, n, 2000); ln = rng.integers(0, 50, 2000)                    # arbitrary (not suffix) intervals
+    keep = lo + ln <= n
+    fp += lo[keep].tolist(); sz += ln[keep].tolist()
+    got = ctx.prefix_all(fp, sz)
+    want = np.array([orc.prefix_all(f, s) for f, s in zip(fp, sz)])
+    assert np.array_equal(got, want)
+    # the forward half of bwt_query_all at the prefix end is the same extension
+    q = ctx.query_all(ma.QUERY_PREFIX, fp, np.zeros(len(fp), np.int64), sz)
+    assert np.array_equal(q[:, :, 0], got[:, :, 0]) and np.array_equal(q[:, :, 2], got[:, :, 1])
+    bad = ctx.prefix_all([-1, 0, n + 1, 3], [5, n + 1, 0, -4])
+    assert np.all(bad == -1)
+    assert ctx.prefix_all([], []).shape == (0, 5, 2)
+
+
 def test_sar_get_matches_oracle(small):
     base, ctx, orc = small
     n = orc.txt_len

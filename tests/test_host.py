@@ -29,6 +29,30 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in ma.lib().gpumap_version()
 
 
+def test_header_is_c99_and_the_integration_sketch_compiles_against_the_reference():
+    """include/gpumap.h as a maintainer of the reference would see it: plain C99 (the reference builds with
+    -std=c99, Makefile:16), no HIP or C++ header behind it; and, where the reference's headers are present (this
+    container, not the GPU box), the binding of INTEGRATION.md section 1 (tools/integration/mapper_gpumap.c) compiles
+    against them: every reference function it calls exists with the signature it assumes."""
+    import shutil, subprocess, tempfile
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    inc = os.path.join(ROOT, "include")
+    with tempfile.NamedTemporaryFile("w", suffix=".c") as f:
+        f.write('#include "gpumap.h"\nint main(void) { gpumap_hits h; (void)h; return gpumap_version() == 0; }\n')
+        f.flush()
+        r = subprocess.run([gcc, "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", inc, f.name],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    ref = "/root/reference/src"
+    if not os.path.isfile(os.path.join(ref, "mapper.h")):
+        pytest.skip("the reference's headers are not on this machine")
+    r = subprocess.run([gcc, "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", ref, "-I", inc,
+                        os.path.join(ROOT, "tools", "integration", "mapper_gpumap.c")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
 def test_library_contains_gfx950_code_object():
     blob = open(ma.LIB_PATH, "rb").read()
     assert b"amdgcn-amd-amdhsa--gfx950" in blob and b"k_search" in blob
