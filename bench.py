@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--chunks", type=int, default=8, help="distinct chunks of reads per GPU resident in HBM")
     ap.add_argument("--depth", type=int, default=3, help="batch objects of the pipeline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive legs (profiling runs)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--waves-per-cu", type=int, default=0)
     ap.add_argument("--verify", type=int, default=-1, help="option 'verify' of the library (-1 = its default by text size)")
@@ -366,7 +367,7 @@ def main():
         }
         if replica:
             out["replica_check"] = replica
-        if world == 1:
+        if world == 1 and not args.no_pcie:
             out["pcie_inclusive"] = pcie_inclusive(ma, ctx, codes, offs, w, args.depth)
         if want_cpu:
             out["cpu_baseline"] = cpu_baseline(ctx if on_device else None, base, codes, offs, w, args.cpu_seconds, gpu_ctx=ctx)

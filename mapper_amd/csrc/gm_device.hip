@@ -1286,6 +1286,9 @@ int fetch_array(FetchDst &d, T **dst, const void *src, int64_t count, hipStream_
 {
    *dst = d.take<T>(count);
    if (!*dst) return -1;
+   // (the runtime's copy, a kernel over the whole device on this platform.  A copy kernel of our own on 16..128
+   // workgroups holds the link's 56 GB/s alone, tools/copy_bench.hip, but beside a running k_search it gets too
+   // small a share of the CUs' memory queues: chunk time 21.5 -> 25.4 .. 27.6 ms at GRCh38 size.)
    if (count > 0 && hipMemcpyAsync(*dst, src, sizeof(T) * (size_t)count, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
    return 0;
 }
