@@ -282,7 +282,8 @@ int           gpumap_batch_stats(const gpumap_batch *batch, int64_t stats[8]);
 ** the search ran again with the exact length), stats[1] = microseconds of the encoding stage of a staged batch,
 ** stats[2] = 1 when the run left compact results, stats[3] = capacity of the hit list in entries, stats[4] = chunks
 ** of 64 nodes that the wavefronts' deques spilled to global memory, stats[5] = suffixes (windows of the text)
-** that k_verify replayed; the rest is 0. */
+** that k_verify and k_verify_group replayed, stats[6] = candidates of three and four suffixes (k_verify_group);
+** stats[7] is 0. */
 int           gpumap_batch_stats_ext(const gpumap_batch *batch, int64_t stats[8]);
 void          gpumap_batch_free(gpumap_batch *batch);
 
@@ -357,7 +358,8 @@ int gpumap_mapper_multi(const char *qfile, const gpumap_index *index, gpumap_ctx
 **   "hit_list_guess" first guess of the hit list's length in entries (0 = from the batch; a short guess costs a second search)
 **   "jump_k"         letters of the jump table (0 = none, -1 = by the size of the text and the free memory)
 **   "verify"         0 = every step on the Occ table; 1 = nodes of one suffix are finished on the text;
-**                    2 = also nodes of two suffixes; -1 = by the size of the text (the default) */
+**                    2 = also nodes of two suffixes; 4 = also nodes of three and four; -1 = by the size of the
+**                    text (the default: 4 from 2^31 symbols on, else 1) */
 int gpumap_set_option(gpumap_ctx *ctx, const char *name, int64_t value);
 const char *gpumap_version(void);
 
