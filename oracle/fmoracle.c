@@ -638,3 +638,226 @@ void orc_batch_free(orc_batch_t *b)
    if (!b) return;
    free(b->status); free(b->hits); free(b->locs); free(b);
 }
+
+/* ---------------------------------------------------------------- neighbour annotation (ann_build) */
+
+#define ANN_NO_INFO 0xFFFF                       /* src/index_ann.h:25 */
+#define ANN_WORD    6                            /* word_size = max(3, tau) + 3 with tau < 4, src/index_ann.c:78, :86 */
+#define ANN_ALN     3                            /* word_size - 3 */
+
+static uint16_t rd16(const uint8_t *p) { uint16_t v; memcpy(&v, p, 2); return v; }
+static void     wr16(uint8_t *p, uint16_t v) { memcpy(p, &v, 2); }
+
+/* aln_positions, src/index_ann.c:882-917 */
+static void ann_aln_positions(const uint64_t *bits, uint8_t *pos, int nbits, int npos, int reverse)
+{
+   uint8_t tmp[ANN_ALN + 1] = {0};
+   int a = 0;
+   for (int i = 0; i < nbits && a <= npos; i++)
+      if ((bits[i / 64] >> (i % 64)) & 1) tmp[a++] = (uint8_t)(reverse ? nbits - i : i + 1);
+   if (a > npos) memset(pos, 0xFF, npos);
+   else memcpy(pos, tmp, npos);
+}
+
+/* aln_merge, src/index_ann.c:833-879 */
+static void ann_aln_merge(uint8_t *a, const uint8_t *b, int len)
+{
+   uint8_t tmp[2 * ANN_ALN + 2] = {0};
+   int i = 0, j = 0, k = 0;
+   while (i < len && j < len && k <= len) {
+      if (a[i] == 0 || b[j] == 0) break;
+      if (a[i] == b[j]) { tmp[k++] = a[i]; i++; j++; }
+      else if (a[i] < b[j]) tmp[k++] = a[i++];
+      else tmp[k++] = b[j++];
+   }
+   while (i < len && k <= len && a[i]) tmp[k++] = a[i++];
+   while (j < len && k <= len && b[j]) tmp[k++] = b[j++];
+   while (k < len) tmp[k++] = 0;
+   if (k > len) memset(a, 0xFF, len);
+   else memcpy(a, tmp, len);
+}
+
+/* hits_push, src/index_ann.c:920-1071: `hits` = tree->stack after blocksc_trail, (fp, rp) = path[kmer]. */
+static void ann_hits_push(uint8_t *info, int kmer, int tau_arg, const orc_hit_t *hits, int64_t n_hits, int64_t fp, int64_t rp)
+{
+   int nh = 0, tau = tau_arg + 1;
+   if (fp > rp) wr16(info + fp * ANN_WORD, ANN_NO_INFO);                          /* :943-947 */
+   const int64_t lo = fp < rp ? fp : rp;
+   if (n_hits < 2) {                                                             /* :950-957 */
+      if (rd16(info + lo * ANN_WORD) == 0) wr16(info + lo * ANN_WORD, ANN_NO_INFO);
+      return;
+   }
+   uint64_t qalign[ORC_ALIGN_WORDS] = {0};
+   for (int64_t i = 0; i < n_hits; i++) {                                        /* :964-1027 */
+      const orc_hit_t *p = &hits[i];
+      if (p->fp == fp) continue;                                                 /* the self hit */
+      const int64_t nptr = p->rp < p->fp ? p->rp : p->fp;
+      const int nrev = p->rp < p->fp;
+      uint8_t *ninfo = info + nptr * ANN_WORD, *ntau = ninfo + 2, *naln = ntau + 1;
+      const uint16_t ncnt = rd16(ninfo);
+      if (*ntau == p->score) {                                                   /* :987-998 */
+         const uint32_t c = (uint32_t)ncnt + 1;
+         wr16(ninfo, (uint16_t)(c < 0xFFFE ? c : 0xFFFE));
+         if (*naln != 0xFF) {
+            uint8_t hit_aln[ANN_ALN];
+            ann_aln_positions(p->align, hit_aln, kmer, ANN_ALN, nrev);
+            ann_aln_merge(naln, hit_aln, ANN_ALN);
+         }
+      } else if (ncnt == 0 || ncnt == ANN_NO_INFO || *ntau > p->score) {           /* :1000-1009 */
+         wr16(ninfo, 1);
+         *ntau = (uint8_t)p->score;
+         uint8_t hit_aln[ANN_ALN];
+         ann_aln_positions(p->align, hit_aln, kmer, ANN_ALN, nrev);
+         memcpy(naln, hit_aln, ANN_ALN);
+      }
+      if (p->score == tau) {                                                     /* :1014-1026 */
+         for (int w = 0; w < ORC_ALIGN_WORDS; w++) qalign[w] |= p->align[w];
+         nh++;
+      } else if (p->score < tau) {
+         memcpy(qalign, p->align, sizeof qalign);
+         tau = (int)p->score;
+         nh = 1;
+      }
+   }
+   const int qrev = rp < fp;                                                     /* :1030-1061 */
+   uint8_t *qi = info + lo * ANN_WORD, *qtau = qi + 2, *qaln = qtau + 1;
+   const uint16_t qcnt = rd16(qi);
+   if (qcnt == 0 || qcnt == ANN_NO_INFO || *qtau > tau) {
+      *qtau = (uint8_t)tau;
+      wr16(qi, (uint16_t)(nh < ANN_NO_INFO - 1 ? nh : ANN_NO_INFO - 1));
+      ann_aln_positions(qalign, qaln, kmer, ANN_ALN, qrev);
+   } else if (*qtau == tau) {
+      const uint32_t c = (uint32_t)nh + (uint32_t)qcnt;
+      wr16(qi, (uint16_t)(c < ANN_NO_INFO - 1 ? c : ANN_NO_INFO - 1));
+      if (*qaln != 0xFF) {
+         uint8_t tmp_aln[ANN_ALN];
+         ann_aln_positions(qalign, tmp_aln, kmer, ANN_ALN, qrev);
+         ann_aln_merge(qaln, tmp_aln, ANN_ALN);
+      }
+   }
+}
+
+/* neigh_push, src/index_ann.c:664-729.  `ann` may point outside the table where the reference's compression attaches
+** unvisited suffix-array entries to a record (see orc_ann_build): those writes are dropped and counted. */
+static void ann_neigh_push(const uint8_t *info, uint8_t *table, int64_t size, int64_t at, int reverse_kmer, int64_t *dropped)
+{
+   const uint16_t cnt = rd16(info);
+   const uint8_t tau = info[2];
+   if (cnt == 0 || cnt == ANN_NO_INFO) return;
+   uint8_t v = 0;
+   if (cnt <= 10) v = (uint8_t)cnt;
+   else if (cnt <= 20) v = 0x0B;
+   else if (cnt <= 50) v = 0x0C;
+   else if (cnt <= 100) v = 0x0D;
+   else if (cnt <= 500) v = 0x0E;
+   else v = 0x0F;
+   v |= (uint8_t)(((tau - 1) & 0x03) << 4);
+   uint8_t aln[ANN_ALN];
+   memcpy(aln, info + 3, ANN_ALN);
+   const int have = aln[0] != 255;
+   if (have) {
+      if (reverse_kmer)
+         for (int k = 0; k < ANN_ALN && aln[k]; k++) aln[k] = (uint8_t)(reverse_kmer + 1 - aln[k]);
+      v |= 1u << 6;
+   }
+   if (at >= 0 && at < size) table[at] |= v; else (*dropped)++;
+   if (have)
+      for (int i = 0; i < ANN_ALN && aln[i]; i++) {
+         const int64_t p = at + aln[i] - 1;
+         if (p >= 0 && p < size) table[p] |= 1u << 7; else (*dropped)++;
+      }
+}
+
+typedef struct { int64_t beg, end; } annjob_t;
+
+/* jobs_by_prefix, src/index_ann.c:612-661 */
+static void ann_jobs(const orc_index_t *x, int64_t fp, int64_t rp, int64_t sz, int tau, int n_cnt, int depth, int max_depth,
+                     annjob_t *jobs, int *n_jobs)
+{
+   if (n_cnt > tau) return;
+   if (depth == max_depth) { jobs[*n_jobs].beg = fp; jobs[*n_jobs].end = fp + sz; (*n_jobs)++; return; }
+   int64_t qv[5][3];
+   orc_extend_all(x, ORC_QUERY_SUFFIX, fp, rp, sz, qv);
+   for (int i = 0; i < 5; i++)
+      ann_jobs(x, qv[i][0], qv[i][1], qv[i][2], tau, n_cnt + (i == ORC_UNKNOWN_BASE), depth + 1, max_depth, jobs, n_jobs);
+}
+
+/* ann_build (src/index_ann.c:56-257) + ann_build_mt (:500-609) + neigh_next (:732-830), the jobs run one after the
+** other in the order of the job list (what the reference does with threads = 1; `threads` only sets the depth of the
+** prefixes the jobs are cut at, :116-121).  Every k-mer is searched afresh (orc_blocksc: trail = 0): the reference's
+** reuse of the last k-mer's left block is exact except next to k-mers with N (tests/test_oracle_blocksc.py).
+** table: [txt_len / 2] bytes, the content of ann->info (what ann_file_write stores behind its 32-byte header).
+** Returns 0, -1 on bad arguments (:76-82); *dropped = writes of the compression that fell outside the table. */
+int orc_ann_build(const orc_index_t *x, int kmer, int tau, int threads, uint8_t *table, int64_t *n_queries, int64_t *n_ext_out,
+                  int64_t *dropped_out)
+{
+   if (kmer < 2 || tau < 1 || tau >= 4 || tau >= kmer || threads < 1 || !x || !table) return -1;
+   const int64_t tlen = x->txt_len;
+   uint8_t *info = calloc((size_t)tlen, ANN_WORD);
+   if (!info) return -1;
+   int depth = 1, num_jobs = 5;
+   while (num_jobs < 5 * threads) { depth++; num_jobs *= 5; }
+   annjob_t *jobs = malloc(sizeof *jobs * (size_t)num_jobs);
+   int nj = 0;
+   ann_jobs(x, 0, 0, tlen, tau, 0, 0, depth, jobs, &nj);
+   uint8_t *seq = malloc((size_t)kmer);
+   int64_t n_q = 0, n_ext = 0, dropped = 0;
+   for (int j = 0; j < nj; j++) {
+      int64_t sa_ptr = jobs[j].beg;
+      while (sa_ptr < jobs[j].end) {
+         /* neigh_next */
+         const int64_t txt_pos = orc_sar_get(x, sa_ptr);
+         int64_t next_sa = sa_ptr + 1;
+         int valid = txt_pos + kmer <= tlen;                                     /* :765 */
+         for (int i = 0; valid && i < kmer; i++) valid = x->text[txt_pos + i] < 5;   /* :773-777 */
+         int64_t fp = 0, rp = 0, sz = tlen;
+         if (valid) {
+            int n_cnt = 0;
+            for (int i = 0; i < kmer; i++) {
+               seq[i] = x->text[txt_pos + i];
+               n_cnt += seq[i] == ORC_UNKNOWN_BASE;
+               int64_t qv[5][3];
+               orc_extend_all(x, ORC_QUERY_SUFFIX, fp, rp, sz, qv);               /* :791 */
+               fp = qv[seq[i]][0]; rp = qv[seq[i]][1]; sz = qv[seq[i]][2];
+            }
+            if (sz == 0) valid = 0;                                               /* :798 */
+            else {
+               next_sa = sa_ptr + sz;                                             /* :804 */
+               if (n_cnt > tau) valid = 0;                                        /* :807 */
+            }
+         }
+         if (!valid) {
+            wr16(info + sa_ptr * ANN_WORD, ANN_NO_INFO);                          /* :559-561 */
+         } else {
+            orc_hit_t *hits = NULL;
+            int64_t ne = 0;
+            int64_t nh = orc_blocksc(x, seq, kmer, tau, &hits, &ne);              /* :564-567; its return value is not looked at */
+            if (nh < 0) nh = 0;                                                   /* (the stack was emptied before the error) */
+            n_q++; n_ext += ne;
+            ann_hits_push(info, kmer, tau, hits, nh, fp, rp);                     /* :569 */
+            free(hits);
+         }
+         sa_ptr = next_sa;
+      }
+   }
+   /* compression, :200-241 */
+   memset(table, 0, (size_t)(tlen / 2));
+   int64_t i = 0;
+   while (1) {
+      while (i < tlen && (rd16(info + i * ANN_WORD) == ANN_NO_INFO || rd16(info + i * ANN_WORD) == 0)) i++;
+      if (i >= tlen) break;
+      int64_t size = 1;
+      while (i + size < tlen && rd16(info + (i + size) * ANN_WORD) == 0) size++;
+      for (int64_t k = 0; k < size; k++) {
+         const int64_t p = orc_sar_get(x, i + k);
+         if (p >= tlen / 2) ann_neigh_push(info + i * ANN_WORD, table, tlen / 2, tlen - p - kmer, kmer, &dropped);
+         else ann_neigh_push(info + i * ANN_WORD, table, tlen / 2, p, 0, &dropped);
+      }
+      i += size;
+   }
+   free(seq); free(jobs); free(info);
+   if (n_queries) *n_queries = n_q;
+   if (n_ext_out) *n_ext_out = n_ext;
+   if (dropped_out) *dropped_out = dropped;
+   return 0;
+}

@@ -312,14 +312,33 @@ static int cmd_kat(int argc, char **argv)
    return 0;
 }
 
+/* ann <base> <kmer> <tau> <threads> <out.ann>: the reference's own ann_build (src/index_ann.c:56-257) on the index
+** files of <base>, written with its own ann_file_write (:384-434).  The progress lines go to stderr. */
+static int cmd_ann(int argc, char **argv)
+{
+   if (argc < 7) return 2;
+   index_t *index = index_read(argv[2]);
+   if (index == NULL) { fprintf(stderr, "ref_driver: index_read failed\n"); return 1; }
+   double t0 = now_s();
+   ann_t *ann = ann_build(atoi(argv[3]), atoi(argv[4]), index->bwt, index->sar, atoi(argv[5]));
+   if (ann == NULL) { fprintf(stderr, "ref_driver: ann_build failed\n"); return 1; }
+   double t1 = now_s();
+   if (ann_file_write(argv[6], ann) == -1) { fprintf(stderr, "ref_driver: ann_file_write failed\n"); return 1; }
+   printf("{\"kind\": \"reference\", \"kmer\": %d, \"tau\": %d, \"threads\": %d, \"txt_len\": %ld, \"seconds\": %.3f}\n",
+          atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), (long)txt_length(index->txt), t1 - t0);
+   ann_free(ann);
+   return 0;
+}
+
 int main(int argc, char **argv)
 {
+   if (argc >= 2 && strcmp(argv[1], "ann") == 0) return cmd_ann(argc, argv);
    if (argc >= 2 && strcmp(argv[1], "build") == 0) return cmd_build(argc, argv);
    if (argc >= 2 && strcmp(argv[1], "map") == 0) return cmd_map(argc, argv, 0);
    if (argc >= 2 && strcmp(argv[1], "sc") == 0) return cmd_map(argc, argv, 1);
    if (argc >= 2 && strcmp(argv[1], "sctrail") == 0) return cmd_map(argc, argv, 2);
    if (argc >= 2 && strcmp(argv[1], "kat") == 0) return cmd_kat(argc, argv);
    fprintf(stderr, "usage: ref_driver build <ref.fa> <base> | map <base> <reads.txt> <tau> <out.bin> [threads]"
-                   " | kat <spec> <out.txt>\n");
+                   " | kat <spec> <out.txt> | ann <base> <kmer> <tau> <threads> <out.ann>\n");
    return 2;
 }
