@@ -337,6 +337,24 @@ int           gpumap_multi_map_batch(gpumap_multi *multi, const uint8_t *codes, 
 void          gpumap_multi_destroy(gpumap_multi *multi);
 
 /* ------------------------------------------------------------------------------------------
+** ann_build(kmer, tau, bwt, sar, threads) (src/index_ann.c:56-257), the reference's consumer of blocksc_trail: for
+** every distinct k-mer of the text (in suffix-array order, ann_build_mt :500-609) the neighbours within tau mismatches,
+** folded into one byte per position of the forward strand (hits_push :920-1071, neigh_push :664-729): bits 0-3 the
+** class of the number of closest neighbours, bits 4-5 their distance - 1, bit 6 "mismatch positions known", bit 7
+** "a closest neighbour of the k-mer that starts at an earlier marked position differs here".  `table` (host,
+** txt_len / 2 bytes) = ann->info of the reference with threads = 1, except next to k-mers with N, where the reference
+** reuses the search of another k-mer: every k-mer is searched afresh here, what blocksc_trail
+** computes with trail = 0.  Needs a context that holds the text; texts below 2^31 symbols.  stats (may be NULL):
+** [0] k-mers searched, [1] extension steps, [2] hits, [3] updates of records, [4] microseconds on the device.
+** gpumap_ann_query = ann_query (:278-347) on such a table (align_pos: room for kmer entries, may be NULL);
+** gpumap_ann_file_write = ann_file_write (:384-434): the file index_read picks up as <base>.ann.<kmer>.<tau>.
+** ---------------------------------------------------------------------------------------- */
+int gpumap_ann_build(gpumap_ctx *ctx, int kmer, int tau, uint8_t *table, int64_t stats[8]);
+int gpumap_ann_query(const uint8_t *table, int64_t size, int kmer, int64_t pos, int32_t *dist, int32_t *neigh_cnt,
+                     int32_t *align_cnt, int32_t *align_pos);
+int gpumap_ann_file_write(const char *filename, const uint8_t *table, int64_t size, int kmer, int tau);
+
+/* ------------------------------------------------------------------------------------------
 ** mapper() (src/mapper.c:3-47, src/mapper.h:10): reads `qfile` (FASTQ / FASTA / raw, detected
 ** as io_stream_set_parser does, src/io.c:232-266) in chunks, maps each chunk on the GPU and
 ** writes one line per located hit to `out_path` (NULL or "-" = stdout):

@@ -85,6 +85,9 @@ API = {
     "gpumap_query_all": (_I, [_P, _I, _I64, _P, _P, _P, _P]),
     "gpumap_query_all_noalloc": (_I, [_P, _I, _I64, _P, _P, _P, _P]),
     "gpumap_prefix_all": (_I, [_P, _I64, _P, _P, _P]),
+    "gpumap_ann_build": (_I, [_P, _I, _I, _P, _P]),
+    "gpumap_ann_query": (_I, [_P, _I64, _I, _I64, _P, _P, _P, _P]),
+    "gpumap_ann_file_write": (_I, [C.c_char_p, _P, _I64, _I, _I]),
     "gpumap_sar_get": (_I, [_P, _I64, _P, _P]),
     "gpumap_sar_get_range": (_I, [_P, _I64, _I64, _P]),
     "gpumap_encode": (_I, [_P, _P, _P, _I64, _P]),
@@ -379,6 +382,16 @@ class Multi:
             pass
 
 
+def ann_query(table, kmer, pos):
+    """gpumap_ann_query: (dist, neigh_cnt, align positions) of the reference's locinfo_t."""
+    table = np.ascontiguousarray(table, dtype=np.uint8)
+    d, c, a = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    pos_out = np.zeros(max(kmer, 1), dtype=np.int32)
+    if lib().gpumap_ann_query(_ptr(table), len(table), kmer, pos, C.byref(d), C.byref(c), C.byref(a), _ptr(pos_out)) != 0:
+        raise GpumapError("gpumap_ann_query failed")
+    return d.value, c.value, pos_out[:a.value].tolist()
+
+
 class Pipe:
     """gpumap_pipe: chunks in, results out in the same order, the stages of consecutive chunks overlapping."""
 
@@ -523,6 +536,16 @@ class Context:
         if lib().gpumap_prefix_all(self._h, len(fp), _ptr(fp), _ptr(sz), _ptr(out)) != 0:
             raise GpumapError("gpumap_prefix_all failed")
         return out
+
+    def ann_build(self, kmer, tau):
+        """gpumap_ann_build: the annotation table (txt_len / 2 bytes) and the work figures."""
+        txt_len = int(self.export()[1][:16].view(np.int64)[1])        # (the header of an exported index: magic, n, ...)
+        table = np.zeros(txt_len // 2, dtype=np.uint8)
+        stats = np.zeros(8, dtype=np.int64)
+        if lib().gpumap_ann_build(self._h, kmer, tau, _ptr(table), _ptr(stats)) != 0:
+            raise GpumapError("gpumap_ann_build failed (see stderr)")
+        return table, {"queries": int(stats[0]), "n_ext": int(stats[1]), "hits": int(stats[2]), "updates": int(stats[3]),
+                       "us": int(stats[4])}
 
     def query_all_noalloc(self, end, fp, rp, sz):
         """gpumap_query_all_noalloc: at most NOALLOC_MAX_QUERIES intervals, staged in the library's static scratch."""

@@ -11,6 +11,7 @@
 #include "gm_devctx.hpp"
 #include "gm_kernels.hpp"
 #include "gm_search.hpp"
+#include "gm_ann.hpp"
 
 using namespace gm;
 
@@ -43,7 +44,7 @@ struct gpumap_batch {
    DevBuf loc_read, loc_pos, loc_fwd, loc_seq, loc_seqpos, loc_strand, loc_score;
    DevBuf hkeys, hkeys_alt, hidx, hidx_alt, hit_read, hit_fp, hit_rp, hit_sz, hit_dp, hit_score, hit_align;
    DevBuf spill, counters, cub_tmp;
-   DevBuf read_row, sc_bound, score_add, row_leaves, row_state;      // blocksc_trail (gm_batch_run with GM_RUN_SC)
+   DevBuf read_row, sc_bound, score_add, row_leaves, row_state, sc_qfp, sc_qrp;      // blocksc_trail (gm_batch_run with GM_RUN_SC)
    DevBuf big_idx, big_cnt, big_off, big_dense, big_keys, vsteps2;   // candidates of three and four suffixes (k_verify_group)
    const unsigned long long *sorted_keys = nullptr;     // the located hits' keys after the sort (in keys or keys_alt)
    int key_pos_bits = 0;
@@ -69,7 +70,7 @@ struct gpumap_batch {
       for (DevBuf *b : {&up_src, &up_off, &seen, &reads, &reads4, &read_len, &len_row, &row_len, &phases, &phase_rec, &phase_lo, &status, &hits, &hit_sizes, &hit_off, &direct, &vsteps, &longer, &keys, &keys_alt,
                         &read_cnt, &read_first, &loc_read, &loc_pos, &loc_fwd, &loc_seq, &loc_seqpos, &loc_strand,
                         &loc_score, &hkeys, &hkeys_alt, &hidx, &hidx_alt, &hit_read, &hit_fp, &hit_rp, &hit_sz,
-                        &hit_dp, &hit_score, &hit_align, &spill, &counters, &cub_tmp, &read_row, &sc_bound, &score_add, &row_leaves, &row_state,
+                        &hit_dp, &hit_score, &hit_align, &spill, &counters, &cub_tmp, &read_row, &sc_bound, &score_add, &row_leaves, &row_state, &sc_qfp, &sc_qrp,
                         &big_idx, &big_cnt, &big_off, &big_dense, &big_keys, &vsteps2})
          b->release();
       for (auto &e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
@@ -890,6 +891,8 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
          HIP_TRY(b->read_row.ensure(2 * (size_t)std::max<int64_t>(R, 1)));
          HIP_TRY(b->sc_bound.ensure(8 * (size_t)std::max<int64_t>(R, 1)));
          HIP_TRY(b->score_add.ensure((size_t)std::max<int64_t>(R, 1)));
+         HIP_TRY(b->sc_qfp.ensure(8 * (size_t)std::max<int64_t>(R, 1)));
+         HIP_TRY(b->sc_qrp.ensure(8 * (size_t)std::max<int64_t>(R, 1)));
          HIP_TRY(hipMemcpyAsync(b->row_leaves.p, h_leaves, row_leaves.size(), hipMemcpyHostToDevice, st));
          HIP_TRY(hipMemcpyAsync(b->row_state.p, h_state, row_state.size(), hipMemcpyHostToDevice, st));
       }
@@ -897,7 +900,7 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
          hipLaunchKernelGGL(k_sc_prepare, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, st, ctx->ix, b->reads.as<const uint8_t>(),
                             b->read_len.as<const uint16_t>(), b->len_row.as<const uint16_t>(), b->row_state.as<const uint8_t>(), R,
                             b->stride, tau, b->read_row.as<uint16_t>(), b->sc_bound.as<int64_t>(), b->score_add.as<uint8_t>(),
-                            b->status.as<int64_t>());
+                            b->status.as<int64_t>(), b->sc_qfp.as<int64_t>(), b->sc_qrp.as<int64_t>());
          HIP_TRY(hipGetLastError());
       } else if (R > 0) {
          hipLaunchKernelGGL(k_status, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, st, b->read_len.as<const uint16_t>(),
@@ -1445,4 +1448,126 @@ extern "C" int gpumap_map_batch(gpumap_ctx *ctx, const uint8_t *codes, const int
 failure_return:
    if (ctx == nullptr || b != ctx->map_batch_obj) gpumap_batch_free(b);
    return -1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ann_build (src/index_ann.c:56-257) on the device: see gm_ann.hpp.  The k-mers are searched in chunks through the
+// batch machinery above (gm_batch_run with GM_RUN_SC and interval output: blocksc_trail per k-mer, trail = 0).
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct IsQuery {
+   __host__ __device__ uint8_t operator()(uint8_t c) const { return (uint8_t)((c & 3) == ANN_CLS_QUERY); }
+};
+struct MaxOwner {
+   __host__ __device__ int64_t operator()(int64_t a, int64_t b) const { return a > b ? a : b; }
+};
+}  // namespace
+
+extern "C" int gpumap_ann_build(gpumap_ctx *ctx, int kmer, int tau, uint8_t *table, int64_t stats[8])
+{
+   gpumap_batch *b = nullptr;
+   DevBuf cls, rec, owner, d_table, q_sa, n_sel, codes, offs, ukey, ukey2, uval, uval2, tmp;
+   int rc = -1;
+   GM_FAIL_IF(ctx == nullptr, "argument 'ctx' is NULL.");
+   GM_FAIL_IF(table == nullptr, "argument 'table' is NULL.");
+   GM_FAIL_IF(kmer < 2, "argument 'kmer' must be greater than 1.");                // src/index_ann.c:76-79
+   GM_FAIL_IF(tau < 1, "argument 'tau' must be greater than 0.");
+   GM_FAIL_IF(tau >= 4, "argument 'tau' must be less than 4.");
+   GM_FAIL_IF(tau >= kmer, "incompatible arguments (tau >= kmer).");
+   GM_FAIL_IF(kmer > 250, "argument 'kmer' must be at most 250 (positions are kept in bytes).");
+   GM_FAIL_IF(ctx->d_text == nullptr, "the context holds no text.");
+   GM_FAIL_IF(ctx->ix.n >= ((int64_t)1 << 31), "the annotation of texts of 2^31 symbols and more is not supported.");
+   HIP_TRY(hipSetDevice(ctx->device));
+   {
+      const int64_t n = ctx->ix.n, half = n / 2;
+      const uint8_t *text = (const uint8_t *)ctx->d_text;
+      hipStream_t st = ctx->stream;
+      const unsigned grid_n = (unsigned)cdiv(n, 256);
+      int64_t n_ext = 0, n_hits = 0, n_updates = 0;
+      hipEvent_t e0, e1;
+      HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+      HIP_TRY(hipEventRecord(e0, st));
+      HIP_TRY(cls.ensure((size_t)n + 8));
+      HIP_TRY(rec.ensure(8 * (size_t)n));
+      HIP_TRY(d_table.ensure((size_t)half + 8));
+      HIP_TRY(hipMemsetAsync(cls.p, 0, (size_t)n + 8, st));
+      HIP_TRY(hipMemsetAsync(rec.p, 0, 8 * (size_t)n, st));
+      HIP_TRY(hipMemsetAsync(d_table.p, 0, (size_t)half + 8, st));
+      hipLaunchKernelGGL(k_ann_classify, dim3(grid_n), dim3(256), 0, st, ctx->ix, text, kmer, tau, cls.as<uint8_t>());
+      HIP_TRY(hipGetLastError());
+      // the k-mers to search, in suffix-array order
+      HIP_TRY(q_sa.ensure(8 * (size_t)n));
+      HIP_TRY(n_sel.ensure(8));
+      int64_t n_q = 0;
+      {
+         hipcub::CountingInputIterator<int64_t> idx(0);
+         hipcub::TransformInputIterator<uint8_t, IsQuery, const uint8_t *> flags(cls.as<const uint8_t>(), IsQuery());
+         size_t bytes = 0;
+         HIP_TRY(hipcub::DeviceSelect::Flagged(nullptr, bytes, idx, flags, q_sa.as<int64_t>(), n_sel.as<int64_t>(), (int)n, st));
+         HIP_TRY(tmp.ensure(bytes));
+         HIP_TRY(hipcub::DeviceSelect::Flagged(tmp.p, bytes, idx, flags, q_sa.as<int64_t>(), n_sel.as<int64_t>(), (int)n, st));
+         HIP_TRY(hipMemcpyAsync(&n_q, n_sel.p, 8, hipMemcpyDeviceToHost, st));
+         HIP_TRY(hipStreamSynchronize(st));
+      }
+      b = gpumap_batch_new(ctx);
+      GM_FAIL_IF(b == nullptr, "cannot create the batch.");
+      const int64_t chunk = getenv("GPUMAP_ANN_CHUNK") ? std::max<int64_t>(1, atoll(getenv("GPUMAP_ANN_CHUNK"))) : ((int64_t)1 << 22);   // (interval output: < 2^24 queries per batch)
+      for (int64_t c0 = 0; c0 < n_q; c0 += chunk) {
+         const int64_t nq = std::min(chunk, n_q - c0);
+         HIP_TRY(codes.ensure((size_t)nq * (size_t)kmer));
+         HIP_TRY(offs.ensure(8 * (size_t)(nq + 1)));
+         hipLaunchKernelGGL(k_ann_gather, dim3((unsigned)cdiv(nq + 1, 256)), dim3(256), 0, st, ctx->ix, text, q_sa.as<const int64_t>() + c0, nq,
+                            kmer, codes.as<uint8_t>(), offs.as<int64_t>());
+         HIP_TRY(hipGetLastError());
+         HIP_TRY(hipStreamSynchronize(st));               // (the batch works on a stream of its own)
+         GM_FAIL_IF(gm_batch_fill(ctx, b, codes.p, offs.as<const int64_t>(), nq, GM_SRC_DEVICE, false) != 0, "cannot stage the k-mers.");
+         GM_FAIL_IF(gm_batch_run(ctx, b, tau, 1, GM_RUN_SC) != 0, "the search of the k-mers failed.");
+         const int64_t H = b->n_real, U = H + nq;
+         n_ext += b->n_ext; n_hits += H; n_updates += U;
+         for (DevBuf *x : {&ukey, &ukey2, &uval, &uval2}) HIP_TRY(x->ensure(8 * (size_t)U));
+         hipLaunchKernelGGL(k_ann_updates, dim3((unsigned)cdiv(nq, 256)), dim3(256), 0, st, nq, kmer, tau, b->sc_qfp.as<const int64_t>(),
+                            b->sc_qrp.as<const int64_t>(), b->hit_read.as<const int64_t>(), b->hit_fp.as<const int64_t>(),
+                            b->hit_rp.as<const int64_t>(), b->hit_score.as<const int64_t>(), b->hit_align.as<const uint64_t>(), H,
+                            ukey.as<unsigned long long>(), uval.as<unsigned long long>(), cls.as<uint32_t>());
+         HIP_TRY(hipGetLastError());
+         hipcub::DoubleBuffer<unsigned long long> dk(ukey.as<unsigned long long>(), ukey2.as<unsigned long long>());
+         hipcub::DoubleBuffer<unsigned long long> dv(uval.as<unsigned long long>(), uval2.as<unsigned long long>());
+         size_t bytes = 0;
+         const int end_bit = std::min(64, 8 + ctx->ix.sar_bits + 1);
+         HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, dk, dv, (int)U, 0, end_bit, st));
+         HIP_TRY(tmp.ensure(bytes));
+         HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, bytes, dk, dv, (int)U, 0, end_bit, st));
+         hipLaunchKernelGGL(k_ann_fold, dim3((unsigned)cdiv(U, 256)), dim3(256), 0, st, (const unsigned long long *)dk.Current(),
+                            (const unsigned long long *)dv.Current(), U, rec.as<uint64_t>());
+         HIP_TRY(hipGetLastError());
+         HIP_TRY(hipStreamSynchronize(st));
+      }
+      // the compression
+      HIP_TRY(owner.ensure(8 * (size_t)n));
+      hipLaunchKernelGGL(k_ann_state, dim3(grid_n), dim3(256), 0, st, rec.as<const uint64_t>(), cls.as<const uint8_t>(), n, owner.as<int64_t>());
+      {
+         size_t bytes = 0;
+         HIP_TRY(hipcub::DeviceScan::InclusiveScan(nullptr, bytes, owner.as<int64_t>(), owner.as<int64_t>(), MaxOwner(), (int)n, st));
+         HIP_TRY(tmp.ensure(bytes));
+         HIP_TRY(hipcub::DeviceScan::InclusiveScan(tmp.p, bytes, owner.as<int64_t>(), owner.as<int64_t>(), MaxOwner(), (int)n, st));
+      }
+      hipLaunchKernelGGL(k_ann_push, dim3(grid_n), dim3(256), 0, st, ctx->ix, rec.as<const uint64_t>(), owner.as<const int64_t>(), kmer,
+                         d_table.as<uint32_t>());
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipMemcpyAsync(table, d_table.p, (size_t)half, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipEventRecord(e1, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      float ms = 0;
+      HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+      (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+      if (stats) {
+         stats[0] = n_q; stats[1] = n_ext; stats[2] = n_hits; stats[3] = n_updates; stats[4] = (int64_t)(1000.0f * ms);
+         stats[5] = stats[6] = stats[7] = 0;
+      }
+   }
+   rc = 0;
+failure_return:
+   gpumap_batch_free(b);
+   for (DevBuf *x : {&cls, &rec, &owner, &d_table, &q_sa, &n_sel, &codes, &offs, &ukey, &ukey2, &uval, &uval2, &tmp}) x->release();
+   return rc;
 }

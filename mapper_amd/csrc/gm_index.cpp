@@ -471,3 +471,50 @@ extern "C" int gpumap_pos_to_str(const gpumap_index *ix, int64_t pos, char *buf,
 failure_return:
    return -1;
 }
+
+// ann_query (src/index_ann.c:278-347) on a table of gpumap_ann_build (= ann->info): distance to the closest
+// neighbours, their number (as the reference decodes its classes, :332-337), the mismatch positions.
+extern "C" int gpumap_ann_query(const uint8_t *table, int64_t size, int kmer, int64_t pos, int32_t *dist, int32_t *neigh_cnt,
+                                int32_t *align_cnt, int32_t *align_pos)
+{
+   GM_FAIL_IF(table == nullptr, "argument 'ann' is NULL.");
+   GM_FAIL_IF(pos < 0, "argument 'pos' must be positive.");
+   GM_FAIL_IF(pos >= size * 2, "index 'pos' out of bounds.");
+   {
+      int strand = 0;
+      if (pos > size) { strand = 1; pos = (size - 1) * 2 - pos; }          // :305-308
+      GM_FAIL_IF(pos < 0 || pos >= size, "index 'pos' out of bounds.");    // (the reference reads outside its table here)
+      const uint8_t info = table[pos];
+      int32_t n_aln = 0;
+      if ((info >> 6) & 1)
+         for (int i = 0; i < kmer && pos + i < size; i++)
+            if ((table[pos + i] >> 7) & 1) { if (align_pos) align_pos[n_aln] = strand ? kmer - 1 - i : i; n_aln++; }
+      const int cnt = info & 0x0F;
+      if (dist) *dist = cnt ? ((info >> 4) & 3) + 1 : 0;
+      if (align_cnt) *align_cnt = n_aln;
+      if (neigh_cnt) *neigh_cnt = cnt <= 10 ? cnt : cnt == 0x0B ? 15 : cnt == 0x0C ? 40 : cnt == 0x0D ? 75 : cnt == 0x0E ? 300 : 1000;
+   }
+   return 0;
+failure_return:
+   return -1;
+}
+
+// ann_file_write (src/index_ann.c:384-434): magic, kmer, tau, size, the table; the file index_read looks for is
+// <base>.ann.<kmer>.<tau> (src/index.c:68-83, :201).
+extern "C" int gpumap_ann_file_write(const char *filename, const uint8_t *table, int64_t size, int kmer, int tau)
+{
+   FILE *f = nullptr;
+   GM_FAIL_IF(filename == nullptr, "argument 'filename' is NULL.");
+   GM_FAIL_IF(table == nullptr, "argument 'ann' is NULL.");
+   f = fopen(filename, "wb");
+   GM_FAIL_IF(f == nullptr, "cannot create the file.");
+   {
+      const int64_t head[4] = {(int64_t)0x0fcb0fcb00050001ll, kmer, tau, size};      // ANN_FILE_MAGICNO, src/index_ann.h:22
+      GM_FAIL_IF(fwrite(head, 8, 4, f) != 4 || (size > 0 && fwrite(table, 1, (size_t)size, f) != (size_t)size), "write error.");
+   }
+   fclose(f);
+   return 0;
+failure_return:
+   if (f) fclose(f);
+   return -1;
+}

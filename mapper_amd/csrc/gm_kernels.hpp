@@ -366,12 +366,13 @@ struct SearchArgs {
 // built every row and knows which are not searched (row_state: 0 search, 1 no hits, 2 error).
 __global__ void __launch_bounds__(256) k_sc_prepare(IndexDev ix, const uint8_t *reads, const uint16_t *read_len, const uint16_t *len_row,
                                                     const uint8_t *row_state, int64_t n_reads, int stride, int tau,
-                                                    uint16_t *read_row, int64_t *sc_bound, uint8_t *score_add, int64_t *status)
+                                                    uint16_t *read_row, int64_t *sc_bound, uint8_t *score_add, int64_t *status,
+                                                    int64_t *q_fp, int64_t *q_rp /* the interval of the whole query (path[kmer] of ann_build_mt) */)
 {
    const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
    if (r >= n_reads) return;
    const int m = read_len[r];
-   read_row[r] = NO_ROW; sc_bound[r] = 0; score_add[r] = 0;
+   read_row[r] = NO_ROW; sc_bound[r] = 0; score_add[r] = 0; q_fp[r] = 0; q_rp[r] = 0;
    if (m < 1 || m > MAX_READ) { status[r] = -1; return; }             // :37; longer than the mismatch bitmap (src/blocksearch.h:12-13)
    uint64_t c[SYMS];
    for (int j = 0; j < SYMS; j++) c[j] = ix.tables[TAB_C + j];
@@ -394,6 +395,7 @@ __global__ void __launch_bounds__(256) k_sc_prepare(IndexDev ix, const uint8_t *
       if (i + 1 == cut_hi) end_hi = fp + sz;
    }
    const int last = fp >= rp;                                           // :55
+   q_fp[r] = fp; q_rp[r] = rp;
    if (n_cnt > tau) { status[r] = 0; return; }                          // :63-66: tau < 0
    const int tau_eff = tau - n_cnt;
    const int row = (len_row[m] * (tau + 1) + tau_eff) * 2 + last;

@@ -768,6 +768,75 @@ static void ann_neigh_push(const uint8_t *info, uint8_t *table, int64_t size, in
       }
 }
 
+/* The reference's reuse of the last k-mer's search (`trail`), as it is: a tree of hit stacks per strand class
+** (alloc_stack_tree, src/blocksearch.c:525-578) that keeps what the last search of each block left there. */
+typedef struct pst { hitvec_t stack; struct pst *l, *r; } pst_t;
+
+static pst_t *pst_new(int blocks)
+{
+   pst_t *n = calloc(1, sizeof *n);
+   if (blocks > 1) { n->l = pst_new((blocks >> 1) + (blocks & 1)); n->r = pst_new(blocks >> 1); }
+   return n;
+}
+
+static void pst_free(pst_t *n)
+{
+   if (!n) return;
+   pst_free(n->l); pst_free(n->r);
+   free(n->stack.v); free(n);
+}
+
+/* blocksearch_trail_rec, src/blocksearch.c:106-177, with its trail argument. */
+static int block_rec_trail(sctx_t *c, int pos, int end, int blocks, int trail, pst_t *node)
+{
+   if (pos < 0 || pos > end || end < 0 || blocks < 0) return -1;     /* :125-128 */
+   node->stack.n = 0;                                                /* :132-135 */
+   if (blocks == 1) {
+      orc_hit_t root;
+      memset(&root, 0, sizeof root);
+      root.sz = c->x->txt_len;
+      search(c, &root, end, pos, -1, 0, 0, 0, &node->stack);
+      return 0;
+   }
+   int blk_l = (blocks >> 1) + (blocks & 1), blk_r = blocks >> 1;
+   int slen = end - pos + 1;
+   int pos_r = pos + (slen >> 1) + (slen & 1), end_l = pos_r - 1;
+   if (trail < pos_r)                                                /* :156-157 */
+      if (block_rec_trail(c, pos, end_l, blk_l, trail, node->l) != 0) return -1;
+   for (int64_t i = 0; i < node->l->stack.n; i++)                    /* :159-162 */
+      search(c, &node->l->stack.v[i], pos_r, end, +1, blocks - 1, (int)node->l->stack.v[i].score, 0, &node->stack);
+   if (block_rec_trail(c, pos_r, end, blk_r, trail, node->r) != 0) return -1;   /* :165 */
+   for (int64_t i = 0; i < node->r->stack.n; i++)                    /* :167-170 */
+      search(c, &node->r->stack.v[i], end_l, pos, -1, blocks - 1, (int)node->r->stack.v[i].score, blk_l, &node->stack);
+   return 0;
+}
+
+/* blocksc_trail, src/blocksearch.c:7-103, with its trail argument; bound[i] = bwt_start + bwt_size of qarray[i]. */
+static void blocksc_trail_emul(sctx_t *c, int slen, int tau, int trail, int last_fragment, const int64_t *bound, pst_t *tree)
+{
+   if (trail >= slen) return;                                        /* :41-43 */
+   tree->stack.n = 0;                                                /* :48-52 */
+   int n_cnt = 0;
+   for (int i = 0; i < slen && n_cnt <= tau; i++) n_cnt += c->q[i] == ORC_UNKNOWN_BASE;
+   tau -= n_cnt;
+   if (tau < 0 || (tau == 0 && !last_fragment)) return;              /* :63-66 */
+   int pos_r = slen / 2 + (last_fragment ? slen % 2 : 0);
+   int tau_l = tau / 2 - (last_fragment ? 0 : (1 - tau % 2));
+   if (trail < pos_r) {                                              /* :73-86 */
+      if (block_rec_trail(c, 0, pos_r - 1, tau_l + 1, trail, tree->l) != 0) return;
+      hitvec_t *ls = &tree->l->stack;
+      int64_t i = 0;
+      while (i < ls->n) {
+         if (ls->v[i].fp < bound[pos_r]) i++;
+         else ls->v[i] = ls->v[--ls->n];
+      }
+   }
+   for (int64_t i = 0; i < tree->l->stack.n; i++)                    /* :89-92 */
+      scsearch(c, &tree->l->stack.v[i], pos_r, slen - 1, tau, (int)tree->l->stack.v[i].score, 0, 1, &tree->stack);
+   if (n_cnt)
+      for (int64_t i = 0; i < tree->stack.n; i++) tree->stack.v[i].score += n_cnt;   /* :95-97 */
+}
+
 typedef struct { int64_t beg, end; } annjob_t;
 
 /* jobs_by_prefix, src/index_ann.c:612-661 */
@@ -784,12 +853,14 @@ static void ann_jobs(const orc_index_t *x, int64_t fp, int64_t rp, int64_t sz, i
 
 /* ann_build (src/index_ann.c:56-257) + ann_build_mt (:500-609) + neigh_next (:732-830), the jobs run one after the
 ** other in the order of the job list (what the reference does with threads = 1; `threads` only sets the depth of the
-** prefixes the jobs are cut at, :116-121).  Every k-mer is searched afresh (orc_blocksc: trail = 0): the reference's
-** reuse of the last k-mer's left block is exact except next to k-mers with N (tests/test_oracle_blocksc.py).
+** prefixes the jobs are cut at, :116-121).  trail_reuse = 1: with the reference's reuse of the last k-mer's search, as
+** it is (a tree of stacks per strand class and job; what a search that returned early or met an N left there is used
+** again): the reference's table, byte for byte.  trail_reuse = 0: every k-mer is searched afresh (orc_blocksc), what
+** blocksc_trail computes for trail = 0; the two differ only next to k-mers with N (tests/test_oracle_ann.py).
 ** table: [txt_len / 2] bytes, the content of ann->info (what ann_file_write stores behind its 32-byte header).
 ** Returns 0, -1 on bad arguments (:76-82); *dropped = writes of the compression that fell outside the table. */
-int orc_ann_build(const orc_index_t *x, int kmer, int tau, int threads, uint8_t *table, int64_t *n_queries, int64_t *n_ext_out,
-                  int64_t *dropped_out)
+int orc_ann_build(const orc_index_t *x, int kmer, int tau, int threads, int trail_reuse, uint8_t *table, int64_t *n_queries,
+                  int64_t *n_ext_out, int64_t *dropped_out)
 {
    if (kmer < 2 || tau < 1 || tau >= 4 || tau >= kmer || threads < 1 || !x || !table) return -1;
    const int64_t tlen = x->txt_len;
@@ -800,10 +871,16 @@ int orc_ann_build(const orc_index_t *x, int kmer, int tau, int threads, uint8_t 
    annjob_t *jobs = malloc(sizeof *jobs * (size_t)num_jobs);
    int nj = 0;
    ann_jobs(x, 0, 0, tlen, tau, 0, 0, depth, jobs, &nj);
-   uint8_t *seq = malloc((size_t)kmer);
+   uint8_t *seq = malloc((size_t)kmer), *query[2] = { malloc((size_t)kmer), malloc((size_t)kmer) };
+   int64_t *bound = malloc(sizeof *bound * (size_t)(kmer + 1));
    int64_t n_q = 0, n_ext = 0, dropped = 0;
    for (int j = 0; j < nj; j++) {
       int64_t sa_ptr = jobs[j].beg;
+      pst_t *tree[2] = { NULL, NULL };
+      if (trail_reuse) {                                                         /* :523-544: per job */
+         tree[0] = pst_new(tau + 1); tree[1] = pst_new(tau + 1);
+         memset(query[0], 5, (size_t)kmer); memset(query[1], 5, (size_t)kmer);
+      }
       while (sa_ptr < jobs[j].end) {
          /* neigh_next */
          const int64_t txt_pos = orc_sar_get(x, sa_ptr);
@@ -811,14 +888,19 @@ int orc_ann_build(const orc_index_t *x, int kmer, int tau, int threads, uint8_t 
          int valid = txt_pos + kmer <= tlen;                                     /* :765 */
          for (int i = 0; valid && i < kmer; i++) valid = x->text[txt_pos + i] < 5;   /* :773-777 */
          int64_t fp = 0, rp = 0, sz = tlen;
+         int trail[2] = { 0, 0 };
          if (valid) {
             int n_cnt = 0;
+            bound[0] = tlen;
             for (int i = 0; i < kmer; i++) {
                seq[i] = x->text[txt_pos + i];
                n_cnt += seq[i] == ORC_UNKNOWN_BASE;
+               if (trail_reuse)                                                   /* :786-789 */
+                  for (int t = 0; t < 2; t++) if (trail[t] == i && seq[i] == query[t][i]) trail[t]++;
                int64_t qv[5][3];
                orc_extend_all(x, ORC_QUERY_SUFFIX, fp, rp, sz, qv);               /* :791 */
                fp = qv[seq[i]][0]; rp = qv[seq[i]][1]; sz = qv[seq[i]][2];
+               bound[i + 1] = fp + sz;
             }
             if (sz == 0) valid = 0;                                               /* :798 */
             else {
@@ -829,16 +911,27 @@ int orc_ann_build(const orc_index_t *x, int kmer, int tau, int threads, uint8_t 
          if (!valid) {
             wr16(info + sa_ptr * ANN_WORD, ANN_NO_INFO);                          /* :559-561 */
          } else {
-            orc_hit_t *hits = NULL;
-            int64_t ne = 0;
-            int64_t nh = orc_blocksc(x, seq, kmer, tau, &hits, &ne);              /* :564-567; its return value is not looked at */
-            if (nh < 0) nh = 0;                                                   /* (the stack was emptied before the error) */
-            n_q++; n_ext += ne;
-            ann_hits_push(info, kmer, tau, hits, nh, fp, rp);                     /* :569 */
-            free(hits);
+            n_q++;
+            if (trail_reuse) {
+               const int lf = fp >= rp;                                           /* :813-819 */
+               memcpy(query[lf], seq, (size_t)kmer);
+               sctx_t c = { x, query[lf], 0, 0 };
+               blocksc_trail_emul(&c, kmer, tau, trail[lf], lf, bound, tree[lf]);
+               n_ext += c.n_ext;
+               ann_hits_push(info, kmer, tau, tree[lf]->stack.v, tree[lf]->stack.n, fp, rp);
+            } else {
+               orc_hit_t *hits = NULL;
+               int64_t ne = 0;
+               int64_t nh = orc_blocksc(x, seq, kmer, tau, &hits, &ne);           /* :564-567; its return value is not looked at */
+               if (nh < 0) nh = 0;                                                /* (the stack was emptied before the error) */
+               n_ext += ne;
+               ann_hits_push(info, kmer, tau, hits, nh, fp, rp);                  /* :569 */
+               free(hits);
+            }
          }
          sa_ptr = next_sa;
       }
+      pst_free(tree[0]); pst_free(tree[1]);
    }
    /* compression, :200-241 */
    memset(table, 0, (size_t)(tlen / 2));
@@ -855,7 +948,7 @@ int orc_ann_build(const orc_index_t *x, int kmer, int tau, int threads, uint8_t 
       }
       i += size;
    }
-   free(seq); free(jobs); free(info);
+   free(seq); free(query[0]); free(query[1]); free(bound); free(jobs); free(info);
    if (n_queries) *n_queries = n_q;
    if (n_ext_out) *n_ext_out = n_ext;
    if (dropped_out) *dropped_out = dropped;

@@ -102,9 +102,10 @@ orc_batch_t *orc_blocksc_batch(const orc_index_t *idx, const uint8_t *codes, con
                                int64_t n_reads, int tau, int threads);
 
 /* ann_build(kmer, tau, bwt, sar, threads) (src/index_ann.c:56-257, workers :500-609, hits_push :920-1071) with the jobs
-** run one after the other; table = ann->info, [txt_len / 2] bytes.  Every k-mer searched afresh (trail = 0). */
-int orc_ann_build(const orc_index_t *idx, int kmer, int tau, int threads, uint8_t *table, int64_t *n_queries,
-                  int64_t *n_ext, int64_t *dropped);
+** run one after the other; table = ann->info, [txt_len / 2] bytes.  trail_reuse = 1: the reference's reuse of the last
+** k-mer's search as it is (its table byte for byte); 0: every k-mer searched afresh (trail = 0). */
+int orc_ann_build(const orc_index_t *idx, int kmer, int tau, int threads, int trail_reuse, uint8_t *table,
+                  int64_t *n_queries, int64_t *n_ext, int64_t *dropped);
 
 /* Whole batch, read-parallel with `threads` pthreads (static partition, private scratch; the
 ** model is ann_build_mt, src/index_ann.c:500-609).  codes: concatenated symbol codes,

@@ -62,7 +62,7 @@ def lib():
                                      C.POINTER(C.c_int64)]
         L.orc_prefix_all.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_int64)]
         L.orc_ann_build.restype = C.c_int
-        L.orc_ann_build.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+        L.orc_ann_build.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                     C.POINTER(C.c_int64)]
         L.orc_sar_get.restype = C.c_int64
         L.orc_sar_get.argtypes = [C.c_void_p, C.c_int64]
@@ -196,12 +196,12 @@ class Index:
         lib().orc_prefix_all(self._h, fp, sz, out)
         return [tuple(out[2 * j:2 * j + 2]) for j in range(5)]
 
-    def ann_build(self, kmer, tau, threads=1):
+    def ann_build(self, kmer, tau, threads=1, trail_reuse=False):
         """ann_build (src/index_ann.c:56-257): the annotation table (ann->info, txt_len / 2 bytes) and the work
         figures (k-mers searched, extension steps, writes of the compression outside the table)."""
         table = np.zeros(self.txt_len // 2, dtype=np.uint8)
         nq, ne, dr = C.c_int64(0), C.c_int64(0), C.c_int64(0)
-        rc = lib().orc_ann_build(self._h, kmer, tau, threads, table.ctypes.data_as(C.c_void_p), C.byref(nq), C.byref(ne), C.byref(dr))
+        rc = lib().orc_ann_build(self._h, kmer, tau, threads, int(trail_reuse), table.ctypes.data_as(C.c_void_p), C.byref(nq), C.byref(ne), C.byref(dr))
         if rc != 0:
             return None, {}
         return table, {"queries": nq.value, "n_ext": ne.value, "dropped": dr.value}
