@@ -317,10 +317,11 @@ def main():
                     "frac_hbm": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else None, "accounting": note_}
         kernels = [
             kern("k_search", k_ms, occ_steps, "extension step on the Occ table", 128, "two 64-B Occ lines per step (SURVEY 8d)"),
-            kern("k_verify", mean["k_verify"], W, "suffix replayed on the text", 232,
-                 "64 B suffix-array line + 64 B text window + 48 B query planes + 32 B list entry + 24 B key and slot count"),
-            kern("scan + k_place + k_place_long", mean["locate"], H, "list entry", 24.0 + 8.0 * L / max(H, 1),
-                 "24 B per list entry + 8 B per located position (suffix-array lines of intervals not counted)"),
+            kern("k_verify + k_verify_group", mean["k_verify"], W, "suffix replayed on the text", 216,
+                 "64 B suffix-array line + 64 B text window + 48 B query planes + 32 B list entry + 8 B key of a hit (upper bound: one per suffix)"),
+            kern("k_stage_compact + scan + k_place + k_place_long", mean["locate"], L, "located position", 16,
+                 "8-B key read from the blocks' staging slots and written to the dense array (the few hits that are intervals read "
+                 "their suffix-array entries instead; not counted apart)"),
             kern("radix sort + k_read_first", mean["order"], L, "located position", 24,
                  "8-B key read and written once + CSR offset; the sort makes 8 passes over the keys"),
             kern("k_encode + k_pack_planes", mean["encode"], n_reads * w["m"], "letter", 2.375,

@@ -40,12 +40,13 @@ struct gpumap_batch {
    uint8_t *h_small = nullptr;       // page-locked: small read-backs (lengths seen, counters) and uploads (phase tables)
    hipEvent_t ev_seen = nullptr;
    DevBuf reads, reads4, read_len, len_row, row_len, phases, phase_rec, phase_lo, status;
-   DevBuf hits, hit_sizes, hit_off, direct, vsteps, longer, keys, keys_alt, read_cnt, read_first;
+   DevBuf hits, hit_sizes, hit_off, vsteps, longer, keys, keys_alt, read_cnt, read_first;
    DevBuf loc_read, loc_pos, loc_fwd, loc_seq, loc_seqpos, loc_strand, loc_score;
    DevBuf hkeys, hkeys_alt, hidx, hidx_alt, hit_read, hit_fp, hit_rp, hit_sz, hit_dp, hit_score, hit_align;
    DevBuf spill, counters, cub_tmp;
    DevBuf read_row, sc_bound, score_add, row_leaves, row_state, sc_qfp, sc_qrp;      // blocksc_trail (gm_batch_run with GM_RUN_SC)
-   DevBuf big_idx, big_cnt, big_off, big_dense, big_keys, vsteps2;   // candidates of three and four suffixes (k_verify_group)
+   DevBuf stage, stage2, iv_idx, iv_dense, blk_cnt, blk_off, blk_cnt2, blk_off2;      // what the blocks of k_verify / k_verify_group leave (keys, lists) and the scans of their counts
+   DevBuf big_idx, big_dense, vsteps2;   // candidates of three and four suffixes (k_verify_group)
    const unsigned long long *sorted_keys = nullptr;     // the located hits' keys after the sort (in keys or keys_alt)
    int key_pos_bits = 0;
    bool compact = false;             // the last run left keys + CSR offsets only (no structure of arrays)
@@ -67,11 +68,11 @@ struct gpumap_batch {
    int pin_turn = 0;
    void release()
    {
-      for (DevBuf *b : {&up_src, &up_off, &seen, &reads, &reads4, &read_len, &len_row, &row_len, &phases, &phase_rec, &phase_lo, &status, &hits, &hit_sizes, &hit_off, &direct, &vsteps, &longer, &keys, &keys_alt,
+      for (DevBuf *b : {&up_src, &up_off, &seen, &reads, &reads4, &read_len, &len_row, &row_len, &phases, &phase_rec, &phase_lo, &status, &hits, &hit_sizes, &hit_off, &vsteps, &longer, &keys, &keys_alt,
                         &read_cnt, &read_first, &loc_read, &loc_pos, &loc_fwd, &loc_seq, &loc_seqpos, &loc_strand,
                         &loc_score, &hkeys, &hkeys_alt, &hidx, &hidx_alt, &hit_read, &hit_fp, &hit_rp, &hit_sz,
                         &hit_dp, &hit_score, &hit_align, &spill, &counters, &cub_tmp, &read_row, &sc_bound, &score_add, &row_leaves, &row_state, &sc_qfp, &sc_qrp,
-                        &big_idx, &big_cnt, &big_off, &big_dense, &big_keys, &vsteps2})
+                        &big_idx, &big_dense, &vsteps2, &stage, &stage2, &iv_idx, &iv_dense, &blk_cnt, &blk_off, &blk_cnt2, &blk_off2})
          b->release();
       for (auto &e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
       for (hipEvent_t *e : {&ev_seen, &ev_sync, &ev_up}) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
@@ -987,33 +988,39 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
       b->key_pos_bits = pos_bits;
       HIP_TRY(hipEventRecord(b->ev[4], st));
       const bool verified = use_verify != 0 && host_cnt[1] > 0;
+      int64_t n_stage1 = 0, n_stage2 = 0, n_iv = 0;        // keys k_verify / k_verify_group left, entries that are intervals
+      unsigned int vblocks = 0, gblocks = 0;
       if (verified) {
          const int64_t H = (int64_t)host_cnt[1];
          GM_FAIL_IF(H >= ((int64_t)1 << 31), "too many entries in the hit list (split the batch).");
-         HIP_TRY(b->hit_sizes.ensure(8 * (size_t)(H + 1)));
-         HIP_TRY(b->direct.ensure(16 * (size_t)H));
-         HIP_TRY(hipMemsetAsync(b->hit_sizes.as<int64_t>() + H, 0, 8, st));
          VerifyArgs V;
          V.ix = ctx->ix; V.text = (const uint8_t *)ctx->d_text; V.text4 = (const uint8_t *)ctx->d_text4;
          V.reads4 = b->reads4.as<const uint8_t>();
          V.reads = b->reads.as<const uint8_t>(); V.row_len = b->row_len.as<const uint16_t>();
          V.phase_rec = b->phase_rec.as<const uint2>(); V.phase_lo = b->phase_lo.as<const uint8_t>();
          V.list = b->hits.as<const Node>(); V.n_list = H; V.stride = b->stride;
-         V.direct = b->direct.as<unsigned long long>(); V.sizes = b->hit_sizes.as<int64_t>();
          V.key_shift = pos_bits + 4;
          const int vbd = 256;
          const bool pairs = use_verify >= 2;                             // two lanes per entry
          const bool groups = use_verify == 4;                            // entries of three and four suffixes go to k_verify_group
          const dim3 vgrid((unsigned)cdiv((pairs ? 2 : 1) * V.n_list, vbd));
+         vblocks = vgrid.x;
          HIP_TRY(b->vsteps.ensure(8 * (size_t)vgrid.x));
          V.n_ext = b->vsteps.as<unsigned long long>();
+         // per block: a slot of keys, a slot of interval entries, their counts (+ one word behind for the scans' totals)
+         HIP_TRY(b->stage.ensure(8 * (size_t)STAGE_PER_BLOCK * vgrid.x));
+         HIP_TRY(b->iv_idx.ensure(4 * (size_t)STAGE_PER_BLOCK * vgrid.x));
+         HIP_TRY(b->blk_cnt.ensure(4 * 3 * ((size_t)vgrid.x + 1)));
+         HIP_TRY(b->blk_off.ensure(4 * 3 * ((size_t)vgrid.x + 1)));
+         HIP_TRY(hipMemsetAsync(b->blk_cnt.p, 0, 4 * 3 * ((size_t)vgrid.x + 1), st));
+         uint32_t *c_stage = b->blk_cnt.as<uint32_t>(), *c_iv = c_stage + (vgrid.x + 1), *c_big = c_iv + (vgrid.x + 1);
+         uint32_t *o_stage = b->blk_off.as<uint32_t>(), *o_iv = o_stage + (vgrid.x + 1), *o_big = o_iv + (vgrid.x + 1);
+         V.stage = b->stage.as<unsigned long long>(); V.stage_cnt = c_stage;
+         V.iv_idx = b->iv_idx.as<uint32_t>(); V.iv_cnt = c_iv;
          V.big_idx = nullptr; V.big_cnt = nullptr;
          if (groups) {
             HIP_TRY(b->big_idx.ensure(4 * (size_t)BIG_PER_BLOCK * vgrid.x));
-            HIP_TRY(b->big_cnt.ensure(4 * ((size_t)vgrid.x + 1)));
-            HIP_TRY(b->big_off.ensure(4 * ((size_t)vgrid.x + 1)));
-            HIP_TRY(hipMemsetAsync(b->big_cnt.as<uint32_t>() + vgrid.x, 0, 4, st));
-            V.big_idx = b->big_idx.as<uint32_t>(); V.big_cnt = b->big_cnt.as<uint32_t>();
+            V.big_idx = b->big_idx.as<uint32_t>(); V.big_cnt = c_big;
          }
 #define GM_VERIFY(N) do { if (pairs) hipLaunchKernelGGL((k_verify<N, true>), vgrid, dim3(vbd), 0, st, V); \
                           else hipLaunchKernelGGL((k_verify<N, false>), vgrid, dim3(vbd), 0, st, V); } while (0)
@@ -1026,28 +1033,44 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
 #undef GM_VERIFY
          hipLaunchKernelGGL(k_sum_steps, dim3(64), dim3(256), 0, st, b->vsteps.as<const unsigned long long>(), (int64_t)vgrid.x, cnt + CNT_WORDS);
          HIP_TRY(hipGetLastError());
-         uint32_t *h_nbig = reinterpret_cast<uint32_t *>(host_cnt + CNT_WORDS + 129);
-         *h_nbig = 0;
-         if (groups) {
+         uint32_t *h_tot = reinterpret_cast<uint32_t *>(host_cnt + CNT_WORDS + 129);      // [0] keys, [1] intervals, [2] big, [3] keys of the groups
+         h_tot[0] = h_tot[1] = h_tot[2] = h_tot[3] = 0;
+         {
             size_t tmp = 0;
-            HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, b->big_cnt.as<uint32_t>(), b->big_off.as<uint32_t>(), (int)vgrid.x + 1, st));
-            HIP_TRY(b->cub_tmp.ensure(tmp));
-            HIP_TRY(hipcub::DeviceScan::ExclusiveSum(b->cub_tmp.p, tmp, b->big_cnt.as<uint32_t>(), b->big_off.as<uint32_t>(), (int)vgrid.x + 1, st));
-            HIP_TRY(hipMemcpyAsync(h_nbig, b->big_off.as<uint32_t>() + vgrid.x, 4, hipMemcpyDeviceToHost, st));
+            const int items = 3 * ((int)vgrid.x + 1);           // the three count arrays lie one behind the other, each with a zero at its end:
+            HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, b->blk_cnt.as<uint32_t>(), b->blk_off.as<uint32_t>(), items, st));
+            HIP_TRY(b->cub_tmp.ensure(tmp));                    // one scan; the offsets of the second and third are taken relative to their first
+            HIP_TRY(hipcub::DeviceScan::ExclusiveSum(b->cub_tmp.p, tmp, b->blk_cnt.as<uint32_t>(), b->blk_off.as<uint32_t>(), items, st));
+            HIP_TRY(hipMemcpyAsync(&h_tot[0], o_stage + vgrid.x, 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(&h_tot[1], o_iv + vgrid.x, 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(&h_tot[2], o_big + vgrid.x, 4, hipMemcpyDeviceToHost, st));
          }
          HIP_TRY(hipMemcpyAsync(host_cnt, cnt, CNT_BYTES, hipMemcpyDeviceToHost, st));
          GM_SYNC(b, st);
-         const int64_t n_big = *h_nbig;
+         n_stage1 = h_tot[0];
+         n_iv = (int64_t)h_tot[1] - (int64_t)h_tot[0];
+         const int64_t n_big = (int64_t)h_tot[2] - (int64_t)h_tot[1];
+         if (n_iv > 0) {
+            HIP_TRY(b->iv_dense.ensure(4 * (size_t)n_iv));
+            hipLaunchKernelGGL(k_list_compact, vgrid, dim3(STAGE_PER_BLOCK), 0, st, b->iv_idx.as<const uint32_t>(), (const uint32_t *)c_iv,
+                               (const uint32_t *)o_iv, STAGE_PER_BLOCK, b->iv_dense.as<uint32_t>() - h_tot[0]);
+         }
          if (n_big > 0) {
             constexpr int G = 4;
             HIP_TRY(b->big_dense.ensure(4 * (size_t)n_big));
-            HIP_TRY(b->big_keys.ensure(8 * (size_t)G * (size_t)n_big));
-            hipLaunchKernelGGL(k_big_compact, vgrid, dim3(BIG_PER_BLOCK), 0, st, b->big_idx.as<const uint32_t>(), b->big_cnt.as<const uint32_t>(),
-                               b->big_off.as<const uint32_t>(), b->big_dense.as<uint32_t>());
+            hipLaunchKernelGGL(k_list_compact, vgrid, dim3(BIG_PER_BLOCK), 0, st, b->big_idx.as<const uint32_t>(), (const uint32_t *)c_big,
+                               (const uint32_t *)o_big, BIG_PER_BLOCK, b->big_dense.as<uint32_t>() - h_tot[1]);
             const dim3 ggrid((unsigned)cdiv(G * n_big, vbd));
+            gblocks = ggrid.x;
             HIP_TRY(b->vsteps2.ensure(8 * (size_t)ggrid.x));
-#define GM_GROUP(N) hipLaunchKernelGGL((k_verify_group<N, G>), ggrid, dim3(vbd), 0, st, V, b->big_dense.as<const uint32_t>(), n_big, \
-                                       b->big_keys.as<unsigned long long>(), b->vsteps2.as<unsigned long long>())
+            HIP_TRY(b->stage2.ensure(8 * (size_t)STAGE_PER_BLOCK * ggrid.x));
+            HIP_TRY(b->blk_cnt2.ensure(4 * ((size_t)ggrid.x + 1)));
+            HIP_TRY(b->blk_off2.ensure(4 * ((size_t)ggrid.x + 1)));
+            HIP_TRY(hipMemsetAsync(b->blk_cnt2.p, 0, 4 * ((size_t)ggrid.x + 1), st));
+            VerifyArgs V2 = V;
+            V2.stage = b->stage2.as<unsigned long long>(); V2.stage_cnt = b->blk_cnt2.as<uint32_t>();
+#define GM_GROUP(N) hipLaunchKernelGGL((k_verify_group<N, G>), ggrid, dim3(vbd), 0, st, V2, b->big_dense.as<const uint32_t>(), n_big, \
+                                       b->vsteps2.as<unsigned long long>())
             switch (cdiv(b->maxlen, 64)) {
                case 1:  GM_GROUP(1); break;
                case 2:  GM_GROUP(2); break;
@@ -1057,8 +1080,14 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
 #undef GM_GROUP
             hipLaunchKernelGGL(k_sum_steps, dim3(64), dim3(256), 0, st, b->vsteps2.as<const unsigned long long>(), (int64_t)ggrid.x, cnt + CNT_WORDS + 64);
             HIP_TRY(hipGetLastError());
+            size_t tmp = 0;
+            HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, b->blk_cnt2.as<uint32_t>(), b->blk_off2.as<uint32_t>(), (int)ggrid.x + 1, st));
+            HIP_TRY(b->cub_tmp.ensure(tmp));
+            HIP_TRY(hipcub::DeviceScan::ExclusiveSum(b->cub_tmp.p, tmp, b->blk_cnt2.as<uint32_t>(), b->blk_off2.as<uint32_t>(), (int)ggrid.x + 1, st));
+            HIP_TRY(hipMemcpyAsync(&h_tot[3], b->blk_off2.as<uint32_t>() + ggrid.x, 4, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipMemcpyAsync(host_cnt + CNT_WORDS + 64, cnt + CNT_WORDS + 64, 8 * 64, hipMemcpyDeviceToHost, st));
             GM_SYNC(b, st);
+            n_stage2 = h_tot[3];
          }
          for (int k = 0; k < (n_big > 0 ? 128 : 64); k++) {
             const unsigned long long st_k = host_cnt[CNT_WORDS + k] & 0xffffffffull;
@@ -1080,46 +1109,56 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
 #endif
       b->verify_windows = (int64_t)verify_windows;
 
-      // ---- K3 locate: slots per entry -> scan -> every entry fills its slots
+      // ---- K3 locate: the keys k_verify / k_verify_group left are made dense; the intervals (after a verified search
+      // a short list of entries, else every entry of the list) get their slots by a scan of their sizes and read
+      // their suffix-array entries
       const int64_t H = b->n_hits;
-      int64_t L = 0;
+      const int64_t n_look = verified ? n_iv : H;              // entries the interval path looks at
+      const uint32_t *dense = verified ? b->iv_dense.as<const uint32_t>() : (const uint32_t *)nullptr;
+      int64_t L_iv = 0;
       HIP_TRY(b->read_first.ensure(8 * (size_t)(R + 1)));
-      if (H > 0) {
+      if (n_look > 0) {
          GM_FAIL_IF(H >= ((int64_t)1 << 31), "too many entries in the hit list (split the batch).");
-         HIP_TRY(b->hit_sizes.ensure(8 * (size_t)(H + 1)));
-         HIP_TRY(b->hit_off.ensure(8 * (size_t)(H + 1)));
-         if (!verified) {                           // (k_verify has written the sizes)
-            HIP_TRY(hipMemsetAsync(b->hit_sizes.p, 0, 8 * (size_t)(H + 1), st));
-            hipLaunchKernelGGL(k_hit_sizes, dim3((unsigned)cdiv(H, 256)), dim3(256), 0, st, b->hits.as<const Node>(), H,
-                               b->hit_sizes.as<int64_t>());
-         }
+         HIP_TRY(b->hit_sizes.ensure(8 * (size_t)(n_look + 1)));
+         HIP_TRY(b->hit_off.ensure(8 * (size_t)(n_look + 1)));
+         HIP_TRY(hipMemsetAsync(b->hit_sizes.as<int64_t>() + n_look, 0, 8, st));
+         hipLaunchKernelGGL(k_hit_sizes, dim3((unsigned)cdiv(n_look, 256)), dim3(256), 0, st, b->hits.as<const Node>(), dense, n_look,
+                            b->hit_sizes.as<int64_t>());
          size_t tmp = 0;
-         HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, b->hit_sizes.as<int64_t>(), b->hit_off.as<int64_t>(), (int)(H + 1), st));
+         HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, b->hit_sizes.as<int64_t>(), b->hit_off.as<int64_t>(), (int)(n_look + 1), st));
          HIP_TRY(b->cub_tmp.ensure(tmp));
-         HIP_TRY(hipcub::DeviceScan::ExclusiveSum(b->cub_tmp.p, tmp, b->hit_sizes.as<int64_t>(), b->hit_off.as<int64_t>(), (int)(H + 1), st));
+         HIP_TRY(hipcub::DeviceScan::ExclusiveSum(b->cub_tmp.p, tmp, b->hit_sizes.as<int64_t>(), b->hit_off.as<int64_t>(), (int)(n_look + 1), st));
          int64_t *h_L = reinterpret_cast<int64_t *>(host_cnt + CNT_WORDS + 128);
-         HIP_TRY(hipMemcpyAsync(h_L, b->hit_off.as<int64_t>() + H, 8, hipMemcpyDeviceToHost, st));
+         HIP_TRY(hipMemcpyAsync(h_L, b->hit_off.as<int64_t>() + n_look, 8, hipMemcpyDeviceToHost, st));
          GM_SYNC(b, st);
-         L = *h_L;
+         L_iv = *h_L;
       }
+      const int64_t L = n_stage1 + n_stage2 + L_iv;
       b->n_locs = L;
       if (L > 0) {
          GM_FAIL_IF(L >= ((int64_t)1 << 31), "too many located hits in one batch (split the batch).");
          HIP_TRY(b->keys.ensure(8 * (size_t)L));
          HIP_TRY(b->keys_alt.ensure(8 * (size_t)L));
-         const unsigned int longer_cap = (unsigned int)(L / PLACE_INLINE + 1);
-         HIP_TRY(b->longer.ensure(4 * (size_t)longer_cap));
-         unsigned int *n_longer = (unsigned int *)(cnt + CNT_WORDS + 128);
-         HIP_TRY(hipMemsetAsync(n_longer, 0, 8, st));
-         hipLaunchKernelGGL(k_place, dim3((unsigned)cdiv(H, 256)), dim3(256), 0, st, ctx->ix, b->hits.as<const Node>(), H,
-                            verified ? b->direct.as<const unsigned long long>() : (const unsigned long long *)nullptr,
-                            b->hit_sizes.as<const int64_t>(), b->hit_off.as<const int64_t>(), pos_bits, b->keys.as<unsigned long long>(),
-                            b->longer.as<unsigned int>(), n_longer, longer_cap, sc ? b->score_add.as<const uint8_t>() : (const uint8_t *)nullptr,
-                            b->big_keys.as<const unsigned long long>(), 4);
-         hipLaunchKernelGGL(k_place_long, dim3((unsigned)(4 * ctx->cu_count)), dim3(256), 0, st, ctx->ix, b->hits.as<const Node>(),
-                            b->hit_sizes.as<const int64_t>(), b->hit_off.as<const int64_t>(), pos_bits, b->keys.as<unsigned long long>(),
-                            b->longer.as<const unsigned int>(), (const unsigned int *)n_longer,
-                            sc ? b->score_add.as<const uint8_t>() : (const uint8_t *)nullptr);
+         if (n_stage1 > 0)
+            hipLaunchKernelGGL(k_stage_compact, dim3(vblocks), dim3(STAGE_PER_BLOCK), 0, st, b->stage.as<const unsigned long long>(),
+                               b->blk_cnt.as<const uint32_t>(), b->blk_off.as<const uint32_t>(), b->keys.as<unsigned long long>());
+         if (n_stage2 > 0)
+            hipLaunchKernelGGL(k_stage_compact, dim3(gblocks), dim3(STAGE_PER_BLOCK), 0, st, b->stage2.as<const unsigned long long>(),
+                               b->blk_cnt2.as<const uint32_t>(), b->blk_off2.as<const uint32_t>(), b->keys.as<unsigned long long>() + n_stage1);
+         if (L_iv > 0) {
+            unsigned long long *keys_iv = b->keys.as<unsigned long long>() + n_stage1 + n_stage2;
+            const unsigned int longer_cap = (unsigned int)(L_iv / PLACE_INLINE + 1);
+            HIP_TRY(b->longer.ensure(4 * (size_t)longer_cap));
+            unsigned int *n_longer = (unsigned int *)(cnt + CNT_WORDS + 128);
+            HIP_TRY(hipMemsetAsync(n_longer, 0, 8, st));
+            hipLaunchKernelGGL(k_place, dim3((unsigned)cdiv(n_look, 256)), dim3(256), 0, st, ctx->ix, b->hits.as<const Node>(), dense, n_look,
+                               b->hit_sizes.as<const int64_t>(), b->hit_off.as<const int64_t>(), pos_bits, keys_iv,
+                               b->longer.as<unsigned int>(), n_longer, longer_cap, sc ? b->score_add.as<const uint8_t>() : (const uint8_t *)nullptr);
+            hipLaunchKernelGGL(k_place_long, dim3((unsigned)(4 * ctx->cu_count)), dim3(256), 0, st, ctx->ix, b->hits.as<const Node>(), dense,
+                               b->hit_sizes.as<const int64_t>(), b->hit_off.as<const int64_t>(), pos_bits, keys_iv,
+                               b->longer.as<const unsigned int>(), (const unsigned int *)n_longer,
+                               sc ? b->score_add.as<const uint8_t>() : (const uint8_t *)nullptr);
+         }
          HIP_TRY(hipGetLastError());
       }
       HIP_TRY(hipEventRecord(b->ev[2], st));

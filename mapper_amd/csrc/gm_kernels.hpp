@@ -415,8 +415,8 @@ __global__ void __launch_bounds__(256) k_sc_prepare(IndexDev ix, const uint8_t *
 // count of bwt_query_all calls (one per position visited, the one at which the path dies included).
 // One suffix-array entry and a window of the text replace one Occ line per letter.
 // One thread per entry of the output list of k_search.  A candidate that becomes a hit is finished here:
-// its sort key goes to direct[] (one suffix: its text position is known) and the locate stage only has
-// to move it to its slot; every entry gets its number of slots for the scan of the locate stage.
+// its sort key (one suffix: its text position is known) goes to the block's slot of the staging area, and the
+// locate stage only has to make the slots dense; the entries that are hits already (intervals) are listed for it.
 // ------------------------------------------------------------------------------------------------
 struct VerifyArgs {
    IndexDev ix;
@@ -431,11 +431,17 @@ struct VerifyArgs {
    int64_t n_list;
    int stride;
    unsigned long long *n_ext;      // [blocks of the launch] steps per block (atomics on a few hot words cost a fifth of the kernel)
-   unsigned long long *direct;     // [n_list][2] sort keys of the hits a candidate (one or two suffixes) became, ~0 = none
-   int64_t *sizes;                 // [n_list] slots of the entry in the located output: such hits, or the suffixes of an interval
    int key_shift;                  // key = read << key_shift | text position << 4 | score (as k_place)
-   uint32_t *big_idx, *big_cnt;    // per block of k_verify<*, true>: the entries that hold more than two suffixes (nullptr: there are none)
+   // Per block of the launch, no atomics: the sort keys of the hits its candidates became (a slot of STAGE_PER_BLOCK
+   // keys per block, filled from its start: k_stage_compact makes them dense), the entries that are hits of k_search
+   // itself (intervals: the locate stage reads their suffix-array entries) and the entries that hold more than two
+   // suffixes (k_verify_group), as lists of entry numbers.
+   unsigned long long *stage;
+   uint32_t *stage_cnt;
+   uint32_t *iv_idx, *iv_cnt;
+   uint32_t *big_idx, *big_cnt;    // (nullptr: there are none)
 };
+constexpr int STAGE_PER_BLOCK = 256;     // keys a block of 256 lanes can produce (one per lane)
 
 // The query row and the text window of a candidate are read as bit planes (k_pack_planes: 16 bytes per
 // plane and 128 symbols; every lane of a load touches a line of its own, so the number of load
@@ -701,7 +707,6 @@ __device__ __forceinline__ void verify_block_sums(uint32_t steps, bool mine, uns
                                            (((unsigned long long)s_windows[0] + s_windows[1] + s_windows[2] + s_windows[3]) << 32);
 }
 
-constexpr unsigned long long DIRECT_BIG = ~0ull - 1ull;    // direct[2i]: the entry's keys are in big_keys (k_verify_group), direct[2i+1] = its group
 constexpr int BIG_PER_BLOCK = 128;                         // entries of a k_verify<*, true> block (two lanes each)
 
 // PAIRS: two lanes per entry of the list.  An entry that is a candidate then holds one or two suffixes;
@@ -735,13 +740,13 @@ __global__ void __launch_bounds__(256) k_verify(VerifyArgs A)
       for (int w = 0; w < 2 * NCH; w++) tw[p][w] = 0;
    bool planes = false;                // tw holds this lane's window
    constexpr bool KEEP_PLANES = PAIRS && NCH <= 2;      // (longer reads: the registers cost more than the loads, 4.6 -> 4.9 ms at 150 nt)
+   bool interval = false;              // a hit of k_search itself (not a hole of the list)
    if (i < A.n_list) {
       const uint32_t w5 = A.list[i].w[5];
       cand = w5 >> META_CAND;
       if (!cand && q == 0) {
          const Node &e = A.list[i];
-         A.sizes[i] = (int64_t)e.w[2] | ((int64_t)((e.w[3] >> 16) & 0xff) << 32);
-         *reinterpret_cast<ulonglong2 *>(A.direct + 2 * i) = make_ulonglong2(~0ull, ~0ull);
+         interval = (e.w[2] | ((e.w[3] >> 16) & 0xff)) != 0;
       }
    }
    bool mine = false;                  // this lane replays a suffix
@@ -756,14 +761,12 @@ __global__ void __launch_bounds__(256) k_verify(VerifyArgs A)
       verify_replay<NCH, KEEP_PLANES>(A, nd, q, E, S, QN, tw, planes, steps, key, p0, read, row, phase0, pos0, end0, fw0);
    }
    // ---- the pair: what the partner found (lanes 2k and 2k+1 of a wave; every lane takes part in the exchange)
-   unsigned long long key_o = ~0ull;
    uint32_t steps_o = 0, shared = 0;
    int64_t p0_o = 0;
    uint64_t Eo[NCH];
 #pragma unroll
    for (int c = 0; c < NCH; c++) Eo[c] = 0;
    if (pairs) {
-      key_o = __shfl_xor(key, 1);
       steps_o = (uint32_t)__shfl_xor((int)steps, 1);
       p0_o = __shfl_xor(p0, 1);
 #pragma unroll
@@ -793,44 +796,51 @@ __global__ void __launch_bounds__(256) k_verify(VerifyArgs A)
                                       : verify_walked<NCH>(A, E, Eo, QN, TD, false, p0, p0_o, row, phase0, pos0, end0, fw0);
       shared = min(wk, min(steps, steps_o));
    }
-   if (cand && !big && q == 0) {
-      const bool f0 = key != ~0ull, f1 = key_o != ~0ull;
-      *reinterpret_cast<ulonglong2 *>(A.direct + 2 * i) = make_ulonglong2(f0 ? key : key_o, f0 && f1 ? key_o : ~0ull);
-      A.sizes[i] = (f0 ? 1 : 0) + (f1 ? 1 : 0);
-   }
    steps -= shared;
-   __shared__ uint32_t s_big[4];
-   const unsigned long long bigm = __ballot(big && q == 0);
-   if (PAIRS && (threadIdx.x & 63) == 0) s_big[threadIdx.x >> 6] = (uint32_t)__popcll(bigm);
+   // what the block leaves behind: every lane's own hit key, the interval entries, the big candidates
+   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+   const unsigned long long lt = (1ull << lane) - 1ull;
+   const bool found = cand && !big && key != ~0ull;
+   const unsigned long long foundm = __ballot(found), ivm = __ballot(interval), bigm = __ballot(big && q == 0);
+   __shared__ uint32_t s_cnt[3][4];
+   if (lane == 0) { s_cnt[0][w] = (uint32_t)__popcll(foundm); s_cnt[1][w] = (uint32_t)__popcll(ivm); s_cnt[2][w] = (uint32_t)__popcll(bigm); }
    verify_block_sums(steps, mine, A.n_ext);         // (barrier inside)
-   if (PAIRS && A.big_idx != nullptr) {
-      const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-      uint32_t off = 0, total = 0;
+   uint32_t off[3] = {0, 0, 0}, total[3] = {0, 0, 0};
 #pragma unroll
-      for (int k = 0; k < 4; k++) { if (k < w) off += s_big[k]; total += s_big[k]; }
-      if (big && q == 0)
-         A.big_idx[(size_t)blockIdx.x * BIG_PER_BLOCK + off + (uint32_t)__popcll(bigm & ((1ull << lane) - 1ull))] = (uint32_t)i;
-      if (threadIdx.x == 0) A.big_cnt[blockIdx.x] = total;
+   for (int k = 0; k < 4; k++)
+#pragma unroll
+      for (int t = 0; t < 3; t++) { if (k < w) off[t] += s_cnt[t][k]; total[t] += s_cnt[t][k]; }
+   if (found) A.stage[(size_t)blockIdx.x * STAGE_PER_BLOCK + off[0] + (uint32_t)__popcll(foundm & lt)] = key;
+   if (interval) A.iv_idx[(size_t)blockIdx.x * STAGE_PER_BLOCK + off[1] + (uint32_t)__popcll(ivm & lt)] = (uint32_t)i;
+   if (PAIRS && A.big_idx != nullptr && big && q == 0)
+      A.big_idx[(size_t)blockIdx.x * BIG_PER_BLOCK + off[2] + (uint32_t)__popcll(bigm & lt)] = (uint32_t)i;
+   if (threadIdx.x == 0) {
+      A.stage_cnt[blockIdx.x] = total[0];
+      A.iv_cnt[blockIdx.x] = total[1];
+      if (PAIRS && A.big_idx != nullptr) A.big_cnt[blockIdx.x] = total[2];
    }
 }
 
-// The per-block lists of k_verify made one dense list (off = exclusive scan of the blocks' counts).
-__global__ void __launch_bounds__(BIG_PER_BLOCK) k_big_compact(const uint32_t *big_idx, const uint32_t *big_cnt, const uint32_t *big_off,
-                                                              uint32_t *dense)
+// The per-block slots of the staging area made dense: out[off[b] ..) = the first cnt[b] keys of slot b.
+__global__ void __launch_bounds__(STAGE_PER_BLOCK) k_stage_compact(const unsigned long long *stage, const uint32_t *cnt, const uint32_t *off,
+                                                                    unsigned long long *out)
 {
-   const uint32_t n = big_cnt[blockIdx.x];
-   if (threadIdx.x < n) dense[big_off[blockIdx.x] + threadIdx.x] = big_idx[(size_t)blockIdx.x * BIG_PER_BLOCK + threadIdx.x];
+   if (threadIdx.x < cnt[blockIdx.x]) out[off[blockIdx.x] + threadIdx.x] = stage[(size_t)blockIdx.x * STAGE_PER_BLOCK + threadIdx.x];
+}
+
+// The same for the per-block lists of entry numbers (slots of `per` numbers).
+__global__ void k_list_compact(const uint32_t *idx, const uint32_t *cnt, const uint32_t *off, int per, uint32_t *dense)
+{
+   if (threadIdx.x < cnt[blockIdx.x]) dense[off[blockIdx.x] + threadIdx.x] = idx[(size_t)blockIdx.x * per + threadIdx.x];
 }
 
 // Candidates of three to G suffixes: G lanes per entry, lane q replays suffix q.  The walks of one entry are paths
 // of the reference's search tree from one node; the bwt_query_all calls they stand for are the nodes of the union
 // of those paths: walk q adds its own steps minus the most it shares with any walk before it (two paths share
-// their nodes up to and including the first position where their texts differ: verify_walked).  Keys go to
-// big_keys[group][q]; the entry's number of hits to sizes[], and direct[2i] = DIRECT_BIG, direct[2i+1] = group tell
-// k_place where they are.
+// their nodes up to and including the first position where their texts differ: verify_walked).  The keys of the hits
+// go to the block's slot of the staging area (A.stage, A.stage_cnt: those of this launch), as in k_verify.
 template <int NCH, int G>
-__global__ void __launch_bounds__(256) k_verify_group(VerifyArgs A, const uint32_t *dense, int64_t n_big, unsigned long long *big_keys,
-                                                      unsigned long long *n_ext_out)
+__global__ void __launch_bounds__(256) k_verify_group(VerifyArgs A, const uint32_t *dense, int64_t n_big, unsigned long long *n_ext_out)
 {
    const int64_t th = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
    const int64_t g = th / G;
@@ -886,15 +896,17 @@ __global__ void __launch_bounds__(256) k_verify_group(VerifyArgs A, const uint32
       }
       if (mine && q > j) best = max(best, min(wk, min(steps, steps_o)));
    }
-   // the keys of the hits, packed to the front of the group's G slots
-   const unsigned long long foundm = (__ballot(key != ~0ull) >> base) & ((1ull << G) - 1ull);
-   if (valid && key != ~0ull) big_keys[g * G + __popcll(foundm & ((1ull << q) - 1ull))] = key;
-   if (valid && q == 0) {
-      A.sizes[i] = (int64_t)__popcll(foundm);
-      *reinterpret_cast<ulonglong2 *>(A.direct + 2 * i) = make_ulonglong2(DIRECT_BIG, (unsigned long long)g);
-   }
    steps -= best;
-   verify_block_sums(steps, mine, n_ext_out);
+   const bool found = valid && key != ~0ull;
+   const unsigned long long foundm = __ballot(found);
+   __shared__ uint32_t s_found[4];
+   if (lane == 0) s_found[threadIdx.x >> 6] = (uint32_t)__popcll(foundm);
+   verify_block_sums(steps, mine, n_ext_out);       // (barrier inside)
+   uint32_t off = 0, total = 0;
+#pragma unroll
+   for (int k = 0; k < 4; k++) { if (k < (int)(threadIdx.x >> 6)) off += s_found[k]; total += s_found[k]; }
+   if (found) A.stage[(size_t)blockIdx.x * STAGE_PER_BLOCK + off + (uint32_t)__popcll(foundm & ((1ull << lane) - 1ull))] = key;
+   if (threadIdx.x == 0) A.stage_cnt[blockIdx.x] = total;
 }
 
 // The steps of a k_verify launch: 64 blocks add up the per-block counts, one sum per block (what the host adds up).
@@ -985,75 +997,59 @@ __device__ __forceinline__ void wave_push(WaveQueue &wq, bool flag, const Node &
 // (k_search itself is in gm_search.hpp.)
 
 // ------------------------------------------------------------------------------------------------
-// K3: locate.  hit_off = exclusive scan of the slots per entry of the list.  One thread per entry: a hit
-// k_verify finished brings its key; an interval reads its suffix-array entries (sar_get_range,
-// src/index_sar.c:121-161), up to PLACE_INLINE of them here, longer ones go to a list that k_place_long
-// works through a workgroup per interval.
+// K3: locate.  The hits k_verify / k_verify_group finished are keys already (k_stage_compact).  The hits of k_search
+// itself are intervals: hit_off = exclusive scan of their sizes; one thread per interval reads its suffix-array
+// entries (sar_get_range, src/index_sar.c:121-161), up to PLACE_INLINE of them here, longer ones go to a list that
+// k_place_long works through a workgroup per interval.  After a verified search the intervals are few and come as a
+// list of entry numbers (`dense`); without k_verify every entry of the list is looked at.
 // key = read << (pos_bits + 4) | text position << 4 | score: one radix sort then orders the hits by
 // read and, inside a read, by text position.
 // ------------------------------------------------------------------------------------------------
 constexpr int PLACE_INLINE = 16;
 
-__global__ void k_hit_sizes(const Node *hits, int64_t n_hits, int64_t *sizes)
+// `dense` (may be nullptr): the entries to look at, as a list of entry numbers; sizes / hit_off / longer then count
+// in that list.
+__global__ void k_hit_sizes(const Node *hits, const uint32_t *dense, int64_t n, int64_t *sizes)
 {
-   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-   if (i >= n_hits) return;
-   sizes[i] = (int64_t)hits[i].w[2] | ((int64_t)((hits[i].w[3] >> 16) & 0xff) << 32);
+   int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+   if (t >= n) return;
+   const int64_t i = dense ? dense[t] : t;
+   sizes[t] = (int64_t)hits[i].w[2] | ((int64_t)((hits[i].w[3] >> 16) & 0xff) << 32);
 }
 
-__global__ void __launch_bounds__(256) k_place(IndexDev ix, const Node *hits, int64_t n_hits, const unsigned long long *direct,
+__global__ void __launch_bounds__(256) k_place(IndexDev ix, const Node *hits, const uint32_t *dense, int64_t n,
                                                const int64_t *sizes, const int64_t *hit_off, int pos_bits,
                                                unsigned long long *keys, unsigned int *longer, unsigned int *n_longer, unsigned int longer_cap,
-                                               const uint8_t *score_add /* per read (blocksc_trail adds the N count, :94-97) or nullptr */,
-                                               const unsigned long long *big_keys, int big_g)
+                                               const uint8_t *score_add /* per read (blocksc_trail adds the N count, :94-97) or nullptr */)
 {
-   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-   if (i >= n_hits) return;
-   if (direct) {
-      const ulonglong2 k = *reinterpret_cast<const ulonglong2 *>(direct + 2 * i);
-      if (k.x == DIRECT_BIG) {                     // an entry of k_verify_group: its hits' keys are the first sizes[i] of its four slots
-         const int64_t off = hit_off[i], cnt = sizes[i];
-         if (cnt == 0) return;
-         const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(big_keys + k.y * 4);
-         const ulonglong2 a = src[0], b = src[1];
-         keys[off] = a.x;
-         if (cnt > 1) keys[off + 1] = a.y;
-         if (cnt > 2) keys[off + 2] = b.x;
-         if (cnt > 3) keys[off + 3] = b.y;
-         return;
-      }
-      if (k.x != ~0ull) {
-         const int64_t off = hit_off[i];
-         keys[off] = k.x;
-         if (k.y != ~0ull) keys[off + 1] = k.y;
-         return;
-      }
-   }
-   const int64_t sz = sizes[i];
+   const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+   if (t >= n) return;
+   const int64_t sz = sizes[t];
    if (sz == 0) return;
    if (sz > PLACE_INLINE) {
       const unsigned int slot = atomicAdd(n_longer, 1u);
-      if (slot < longer_cap) longer[slot] = (unsigned int)i;      // (cap = slots / PLACE_INLINE: cannot overflow)
+      if (slot < longer_cap) longer[slot] = (unsigned int)t;      // (cap = slots / PLACE_INLINE: cannot overflow)
       return;
    }
    NodeR h;
-   unpack_node(hits[i], h);
-   const int64_t off = hit_off[i];
+   unpack_node(hits[dense ? dense[t] : t], h);
+   const int64_t off = hit_off[t];
    const unsigned long long hi = ((unsigned long long)h.read << (pos_bits + 4)) | (unsigned long long)(h.score + (score_add ? score_add[h.read] : 0));
    for (int64_t j = 0; j < sz; j++)
       keys[off + j] = hi | ((unsigned long long)sa_entry(ix.sa, ix.sar_bits, h.fp + j) << 4);
 }
 
-__global__ void __launch_bounds__(256) k_place_long(IndexDev ix, const Node *hits, const int64_t *sizes, const int64_t *hit_off, int pos_bits,
+__global__ void __launch_bounds__(256) k_place_long(IndexDev ix, const Node *hits, const uint32_t *dense, const int64_t *sizes,
+                                                    const int64_t *hit_off, int pos_bits,
                                                     unsigned long long *keys, const unsigned int *longer, const unsigned int *n_longer,
                                                     const uint8_t *score_add)
 {
    const unsigned int n = *n_longer;
    for (unsigned int e = blockIdx.x; e < n; e += gridDim.x) {
-      const int64_t i = longer[e];
+      const int64_t t = longer[e];
       NodeR h;
-      unpack_node(hits[i], h);
-      const int64_t off = hit_off[i], sz = sizes[i];
+      unpack_node(hits[dense ? dense[t] : t], h);
+      const int64_t off = hit_off[t], sz = sizes[t];
       const unsigned long long hi = ((unsigned long long)h.read << (pos_bits + 4)) | (unsigned long long)(h.score + (score_add ? score_add[h.read] : 0));
       for (int64_t j = threadIdx.x; j < sz; j += blockDim.x)    // consecutive threads read consecutive packed entries
          keys[off + j] = hi | ((unsigned long long)sa_entry(ix.sa, ix.sar_bits, h.fp + j) << 4);
