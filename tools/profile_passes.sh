@@ -27,7 +27,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum
   timeout -s KILL 300 rocprofv3 --pmc $grp --output-format csv -d $raw/pmc$i -- $B > $raw/pmc$i.json 2> $raw/pmc$i.err || { echo "pmc pass $i ($grp) failed"; tail -5 $raw/pmc$i.err; exit 1; }
 done
 python3 $R/tools/profile_summary.py $raw > $final/summary.json || exit 1
-[ -z "$PMC_ONLY" ] && find $raw/stats -name "*kernel_stats.csv" -exec cp {} $final/kernel_stats.csv \;
+[ -z "$PMC_ONLY" ] && cp "$(ls -S $(find $raw/stats -name "*kernel_stats.csv") | head -1)" $final/kernel_stats.csv   # (the largest: the bench, not the gather microbenchmark it starts)
 cp $raw/*.json $final/ 2>/dev/null
 for d in $raw/pmc*/; do n=$(basename $d); head -1 $d/*/*counter_collection.csv > $final/$n.counters.csv; grep -E "k_search|k_verify|k_place|k_encode" $d/*/*counter_collection.csv >> $final/$n.counters.csv; done
 cat $final/summary.json
