@@ -78,11 +78,12 @@ __device__ __forceinline__ uint64_t ann_fold(uint64_t x, uint64_t y)
    return ann_rec_make(c < 0xfffeu ? c : 0xfffeu, tx, ann_aln_union(ann_rec_aln(x), ann_rec_aln(y)));
 }
 
-// One thread per suffix-array entry.
-__global__ void __launch_bounds__(256) k_ann_classify(IndexDev ix, const uint8_t *text, int kmer, int tau, uint8_t *cls)
+// One thread per suffix-array entry, entries first .. last - 1 (a launch of 2^32 threads and more is cut short by the
+// runtime without an error: the host launches pieces).
+__global__ void __launch_bounds__(256) k_ann_classify(IndexDev ix, const uint8_t *text, int kmer, int tau, uint8_t *cls, int64_t first, int64_t last)
 {
-   const int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x;
-   if (i >= ix.n) return;
+   const int64_t i = first + blockIdx.x * (int64_t)256 + threadIdx.x;
+   if (i >= last) return;
    const int64_t p = sa_entry(ix.sa, ix.sar_bits, i);
    uint8_t c = ANN_CLS_NONE;
    if (text[p] < SYMS) {                                  // the jobs cover the suffixes that start with one of the five symbols (:116-132, threads = 1)
@@ -180,12 +181,18 @@ __global__ void __launch_bounds__(256) k_ann_fold(const unsigned long long *key,
 }
 
 // What the compression sees at entry i (:209, :217): a record, ANN_NO_INFO, or nothing; owner candidate = i unless nothing.
-__global__ void __launch_bounds__(256) k_ann_state(const uint64_t *rec, const uint8_t *cls, int64_t n, int64_t *owner)
+__global__ void __launch_bounds__(256) k_ann_state(const uint64_t *rec, const uint8_t *cls, int64_t first, int64_t last, int64_t *owner)
 {
-   const int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x;
-   if (i >= n) return;
+   const int64_t i = first + blockIdx.x * (int64_t)256 + threadIdx.x;
+   if (i >= last) return;
    const bool something = ann_rec_cnt(rec[i]) != 0 || (cls[i] & (ANN_CLS_FLAG | ANN_CLS_EMPTY)) != 0;
    owner[i] = something ? i : -1;
+}
+
+// The running maximum carried from one piece of the scan into the next.
+__global__ void k_ann_carry(int64_t *owner_piece)
+{
+   if (owner_piece[-1] > owner_piece[0]) owner_piece[0] = owner_piece[-1];
 }
 
 __device__ __forceinline__ void ann_or_byte(uint32_t *table_words, int64_t size, int64_t at, uint32_t v)
@@ -194,10 +201,11 @@ __device__ __forceinline__ void ann_or_byte(uint32_t *table_words, int64_t size,
 }
 
 // neigh_push for every suffix-array entry that a record covers (owner = inclusive running maximum of k_ann_state's).
-__global__ void __launch_bounds__(256) k_ann_push(IndexDev ix, const uint64_t *rec, const int64_t *owner, int kmer, uint32_t *table_words)
+__global__ void __launch_bounds__(256) k_ann_push(IndexDev ix, const uint64_t *rec, const int64_t *owner, int kmer, uint32_t *table_words,
+                                                  int64_t first, int64_t last)
 {
-   const int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x;
-   if (i >= ix.n) return;
+   const int64_t i = first + blockIdx.x * (int64_t)256 + threadIdx.x;
+   if (i >= last) return;
    const int64_t o = owner[i];
    if (o < 0) return;
    const uint64_t r = rec[o];

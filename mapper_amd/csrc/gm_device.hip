@@ -1505,7 +1505,7 @@ struct MaxOwner {
 extern "C" int gpumap_ann_build(gpumap_ctx *ctx, int kmer, int tau, uint8_t *table, int64_t stats[8])
 {
    gpumap_batch *b = nullptr;
-   DevBuf cls, rec, owner, d_table, q_sa, n_sel, codes, offs, ukey, ukey2, uval, uval2, tmp;
+   DevBuf cls, rec, d_table, q_sa, n_sel, codes, offs, ukey, ukey2, uval, uval2, tmp;
    int rc = -1;
    GM_FAIL_IF(ctx == nullptr, "argument 'ctx' is NULL.");
    GM_FAIL_IF(table == nullptr, "argument 'table' is NULL.");
@@ -1515,13 +1515,15 @@ extern "C" int gpumap_ann_build(gpumap_ctx *ctx, int kmer, int tau, uint8_t *tab
    GM_FAIL_IF(tau >= kmer, "incompatible arguments (tau >= kmer).");
    GM_FAIL_IF(kmer > 250, "argument 'kmer' must be at most 250 (positions are kept in bytes).");
    GM_FAIL_IF(ctx->d_text == nullptr, "the context holds no text.");
-   GM_FAIL_IF(ctx->ix.n >= ((int64_t)1 << 31), "the annotation of texts of 2^31 symbols and more is not supported.");
    HIP_TRY(hipSetDevice(ctx->device));
    {
       const int64_t n = ctx->ix.n, half = n / 2;
       const uint8_t *text = (const uint8_t *)ctx->d_text;
       hipStream_t st = ctx->stream;
-      const unsigned grid_n = (unsigned)cdiv(n, 256);
+      // entries per launch of the kernels that run over the suffix array (a launch of 2^32 threads is cut short) and
+      // per call of the device-wide primitives (they count their items in 32 bits)
+      const int64_t piece = getenv("GPUMAP_ANN_PIECE") ? std::max<int64_t>(256, atoll(getenv("GPUMAP_ANN_PIECE"))) : ((int64_t)1 << 30);
+      const int64_t launch_piece = piece;
       int64_t n_ext = 0, n_hits = 0, n_updates = 0;
       hipEvent_t e0, e1;
       HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
@@ -1532,21 +1534,27 @@ extern "C" int gpumap_ann_build(gpumap_ctx *ctx, int kmer, int tau, uint8_t *tab
       HIP_TRY(hipMemsetAsync(cls.p, 0, (size_t)n + 8, st));
       HIP_TRY(hipMemsetAsync(rec.p, 0, 8 * (size_t)n, st));
       HIP_TRY(hipMemsetAsync(d_table.p, 0, (size_t)half + 8, st));
-      hipLaunchKernelGGL(k_ann_classify, dim3(grid_n), dim3(256), 0, st, ctx->ix, text, kmer, tau, cls.as<uint8_t>());
+      for (int64_t f = 0; f < n; f += launch_piece) {
+         const int64_t l = std::min(n, f + launch_piece);
+         hipLaunchKernelGGL(k_ann_classify, dim3((unsigned)cdiv(l - f, 256)), dim3(256), 0, st, ctx->ix, text, kmer, tau, cls.as<uint8_t>(), f, l);
+      }
       HIP_TRY(hipGetLastError());
       // the k-mers to search, in suffix-array order
       HIP_TRY(q_sa.ensure(8 * (size_t)n));
       HIP_TRY(n_sel.ensure(8));
       int64_t n_q = 0;
-      {
-         hipcub::CountingInputIterator<int64_t> idx(0);
-         hipcub::TransformInputIterator<uint8_t, IsQuery, const uint8_t *> flags(cls.as<const uint8_t>(), IsQuery());
+      for (int64_t p0 = 0; p0 < n; p0 += piece) {
+         const int items = (int)std::min(piece, n - p0);
+         hipcub::CountingInputIterator<int64_t> idx(p0);
+         hipcub::TransformInputIterator<uint8_t, IsQuery, const uint8_t *> flags(cls.as<const uint8_t>() + p0, IsQuery());
          size_t bytes = 0;
-         HIP_TRY(hipcub::DeviceSelect::Flagged(nullptr, bytes, idx, flags, q_sa.as<int64_t>(), n_sel.as<int64_t>(), (int)n, st));
+         int64_t got = 0;
+         HIP_TRY(hipcub::DeviceSelect::Flagged(nullptr, bytes, idx, flags, q_sa.as<int64_t>() + n_q, n_sel.as<int64_t>(), items, st));
          HIP_TRY(tmp.ensure(bytes));
-         HIP_TRY(hipcub::DeviceSelect::Flagged(tmp.p, bytes, idx, flags, q_sa.as<int64_t>(), n_sel.as<int64_t>(), (int)n, st));
-         HIP_TRY(hipMemcpyAsync(&n_q, n_sel.p, 8, hipMemcpyDeviceToHost, st));
+         HIP_TRY(hipcub::DeviceSelect::Flagged(tmp.p, bytes, idx, flags, q_sa.as<int64_t>() + n_q, n_sel.as<int64_t>(), items, st));
+         HIP_TRY(hipMemcpyAsync(&got, n_sel.p, 8, hipMemcpyDeviceToHost, st));
          HIP_TRY(hipStreamSynchronize(st));
+         n_q += got;
       }
       b = gpumap_batch_new(ctx);
       GM_FAIL_IF(b == nullptr, "cannot create the batch.");
@@ -1581,17 +1589,25 @@ extern "C" int gpumap_ann_build(gpumap_ctx *ctx, int kmer, int tau, uint8_t *tab
          HIP_TRY(hipGetLastError());
          HIP_TRY(hipStreamSynchronize(st));
       }
-      // the compression
-      HIP_TRY(owner.ensure(8 * (size_t)n));
-      hipLaunchKernelGGL(k_ann_state, dim3(grid_n), dim3(256), 0, st, rec.as<const uint64_t>(), cls.as<const uint8_t>(), n, owner.as<int64_t>());
-      {
-         size_t bytes = 0;
-         HIP_TRY(hipcub::DeviceScan::InclusiveScan(nullptr, bytes, owner.as<int64_t>(), owner.as<int64_t>(), MaxOwner(), (int)n, st));
-         HIP_TRY(tmp.ensure(bytes));
-         HIP_TRY(hipcub::DeviceScan::InclusiveScan(tmp.p, bytes, owner.as<int64_t>(), owner.as<int64_t>(), MaxOwner(), (int)n, st));
+      // the compression (the list of k-mers is done with: its memory holds the owners now)
+      int64_t *own = q_sa.as<int64_t>();
+      for (int64_t f = 0; f < n; f += launch_piece) {
+         const int64_t l = std::min(n, f + launch_piece);
+         hipLaunchKernelGGL(k_ann_state, dim3((unsigned)cdiv(l - f, 256)), dim3(256), 0, st, rec.as<const uint64_t>(), cls.as<const uint8_t>(), f, l, own);
       }
-      hipLaunchKernelGGL(k_ann_push, dim3(grid_n), dim3(256), 0, st, ctx->ix, rec.as<const uint64_t>(), owner.as<const int64_t>(), kmer,
-                         d_table.as<uint32_t>());
+      for (int64_t p0 = 0; p0 < n; p0 += piece) {
+         const int items = (int)std::min(piece, n - p0);
+         if (p0 > 0) hipLaunchKernelGGL(k_ann_carry, dim3(1), dim3(1), 0, st, own + p0);
+         size_t bytes = 0;
+         HIP_TRY(hipcub::DeviceScan::InclusiveScan(nullptr, bytes, own + p0, own + p0, MaxOwner(), items, st));
+         HIP_TRY(tmp.ensure(bytes));
+         HIP_TRY(hipcub::DeviceScan::InclusiveScan(tmp.p, bytes, own + p0, own + p0, MaxOwner(), items, st));
+      }
+      for (int64_t f = 0; f < n; f += launch_piece) {
+         const int64_t l = std::min(n, f + launch_piece);
+         hipLaunchKernelGGL(k_ann_push, dim3((unsigned)cdiv(l - f, 256)), dim3(256), 0, st, ctx->ix, rec.as<const uint64_t>(), (const int64_t *)own,
+                            kmer, d_table.as<uint32_t>(), f, l);
+      }
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipMemcpyAsync(table, d_table.p, (size_t)half, hipMemcpyDeviceToHost, st));
       HIP_TRY(hipEventRecord(e1, st));
@@ -1607,6 +1623,6 @@ extern "C" int gpumap_ann_build(gpumap_ctx *ctx, int kmer, int tau, uint8_t *tab
    rc = 0;
 failure_return:
    gpumap_batch_free(b);
-   for (DevBuf *x : {&cls, &rec, &owner, &d_table, &q_sa, &n_sel, &codes, &offs, &ukey, &ukey2, &uval, &uval2, &tmp}) x->release();
+   for (DevBuf *x : {&cls, &rec, &d_table, &q_sa, &n_sel, &codes, &offs, &ukey, &ukey2, &uval, &uval2, &tmp}) x->release();
    return rc;
 }

@@ -38,8 +38,10 @@ def test_ann_in_chunks_and_on_a_synthetic_text(workdir, monkeypatch):
         got, st = ctx.ann_build(k, tau)
         assert np.array_equal(got, want) and st["n_ext"] == ost["n_ext"]
         monkeypatch.setenv("GPUMAP_ANN_CHUNK", "5000")
+        monkeypatch.setenv("GPUMAP_ANN_PIECE", "4096")            # the suffix array in pieces (texts of 2^31 symbols and more)
         got2, st2 = ctx.ann_build(k, tau)
         monkeypatch.delenv("GPUMAP_ANN_CHUNK")
+        monkeypatch.delenv("GPUMAP_ANN_PIECE")
         assert np.array_equal(got2, want) and st2["queries"] == st["queries"]
         assert np.count_nonzero(want) > 100
     # gpumap_ann_file_write: the file the reference's index_read would pick up

@@ -23,18 +23,33 @@ def main():
     ap.add_argument("--threads", type=int, default=16)
     ap.add_argument("--random", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--device-build", action="store_true", help="generate and index the text in HBM (large texts; no CPU side then)")
+    ap.add_argument("--jump-gb", type=int, default=0, help="cap of the jump table in GiB (0 = the library's default)")
     ap.add_argument("--oracle-max", type=int, default=3_000_000, help="largest text the one-thread restatement is timed on")
     args = ap.parse_args()
     work = tempfile.mkdtemp(prefix="gpumap_ann_")
-    seqs, names = synth.make_genome(args.genome_len, 5, n_seqs=2, gc=0.41, repeat_rich=not args.random)
     base = os.path.join(work, "ref")
-    index = ma.HostIndex.build_codes(seqs, names, base)
-    ctx = ma.Context.from_index(index, 0)
-    ctx.ann_build(args.kmer, args.tau)                       # warm-up (allocations)
+    if args.device_build:
+        import torch
+        from mapper_amd import synth_device
+        g, lens, names = synth_device.make_genome(args.genome_len, 5, n_seqs=24, gc=0.41, repeat_rich=not args.random)
+        ctx = ma.Context.build_device(lens, 0, keep_reference=False, device_ptr=g.data_ptr())
+        del g
+        torch.cuda.empty_cache()
+        args.no_cpu = True
+        n_seqs = 24
+    else:
+        seqs, names = synth.make_genome(args.genome_len, 5, n_seqs=2, gc=0.41, repeat_rich=not args.random)
+        index = ma.HostIndex.build_codes(seqs, names, base)
+        ctx = ma.Context.from_index(index, 0)
+        n_seqs = 2
+        ctx.ann_build(args.kmer, args.tau)                   # warm-up (allocations)
+    if args.jump_gb:
+        ctx.set_option("jump_bytes", args.jump_gb << 30)
     t = time.perf_counter()
     table, st = ctx.ann_build(args.kmer, args.tau)
     gpu_s = time.perf_counter() - t
-    out = {"metric": "gpumap_ann_build: k-mers annotated/s", "kmer": args.kmer, "tau": args.tau, "text_len": int(2 * (args.genome_len + 2)),
+    out = {"metric": "gpumap_ann_build: k-mers annotated/s", "kmer": args.kmer, "tau": args.tau, "text_len": int(2 * (args.genome_len + n_seqs)),
            "genome": "random" if args.random else "repeat-rich", "kmers_searched": st["queries"], "ext_steps": st["n_ext"],
            "hits": st["hits"], "annotated_positions": int(np.count_nonzero(table)),
            "gpu": {"seconds": gpu_s, "device_seconds": st["us"] * 1e-6, "kmers_per_s": st["queries"] / gpu_s}}
