@@ -377,8 +377,9 @@ int gpumap_mapper_multi(const char *qfile, const gpumap_index *index, gpumap_ctx
 **   "hit_list_guess" first guess of the hit list's length in entries (0 = from the batch; a short guess costs a second search)
 **   "jump_k"         letters of the jump table (0 = none, -1 = by the size of the text and the free memory)
 **   "verify"         0 = every step on the Occ table; 1 = nodes of one suffix are finished on the text;
-**                    2 = also nodes of two suffixes; 4 = also nodes of three and four; -1 = by the size of the
-**                    text (the default: 4 from 2^31 symbols on, else 1) */
+**                    2 = also nodes of two suffixes; 4 = also nodes of three and four; 8 / 16 = also nodes of up to
+**                    eight / sixteen (measured slower than 4 at GRCh38 size); -1 = by the size of the text (the
+**                    default: 4 from 2^31 symbols on, else 1) */
 int gpumap_set_option(gpumap_ctx *ctx, const char *name, int64_t value);
 const char *gpumap_version(void);
 

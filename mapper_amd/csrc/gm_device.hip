@@ -45,8 +45,8 @@ struct gpumap_batch {
    DevBuf hkeys, hkeys_alt, hidx, hidx_alt, hit_read, hit_fp, hit_rp, hit_sz, hit_dp, hit_score, hit_align;
    DevBuf spill, counters, cub_tmp;
    DevBuf read_row, sc_bound, score_add, row_leaves, row_state, sc_qfp, sc_qrp;      // blocksc_trail (gm_batch_run with GM_RUN_SC)
-   DevBuf stage, stage2, iv_idx, iv_dense, blk_cnt, blk_off, blk_cnt2, blk_off2;      // what the blocks of k_verify / k_verify_group leave (keys, lists) and the scans of their counts
-   DevBuf big_idx, big_dense, vsteps2;   // candidates of three and four suffixes (k_verify_group)
+   DevBuf stage, stage2[2], iv_idx, iv_dense, blk_cnt, blk_off, blk_cnt2[2], blk_off2[2];      // what the blocks of k_verify / k_verify_group leave (keys, lists) and the scans of their counts
+   DevBuf big_idx, big_dense, wide_idx, wide_dense, vsteps2[2];   // candidates of three and four suffixes (k_verify_group)
    const unsigned long long *sorted_keys = nullptr;     // the located hits' keys after the sort (in keys or keys_alt)
    int key_pos_bits = 0;
    bool compact = false;             // the last run left keys + CSR offsets only (no structure of arrays)
@@ -72,7 +72,8 @@ struct gpumap_batch {
                         &read_cnt, &read_first, &loc_read, &loc_pos, &loc_fwd, &loc_seq, &loc_seqpos, &loc_strand,
                         &loc_score, &hkeys, &hkeys_alt, &hidx, &hidx_alt, &hit_read, &hit_fp, &hit_rp, &hit_sz,
                         &hit_dp, &hit_score, &hit_align, &spill, &counters, &cub_tmp, &read_row, &sc_bound, &score_add, &row_leaves, &row_state, &sc_qfp, &sc_qrp,
-                        &big_idx, &big_dense, &vsteps2, &stage, &stage2, &iv_idx, &iv_dense, &blk_cnt, &blk_off, &blk_cnt2, &blk_off2})
+                        &big_idx, &big_dense, &wide_idx, &wide_dense, &vsteps2[0], &vsteps2[1], &stage, &stage2[0], &stage2[1], &iv_idx, &iv_dense, &blk_cnt, &blk_off,
+                        &blk_cnt2[0], &blk_cnt2[1], &blk_off2[0], &blk_off2[1]})
          b->release();
       for (auto &e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
       for (hipEvent_t *e : {&ev_seen, &ev_sync, &ev_up}) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
@@ -83,6 +84,7 @@ struct gpumap_batch {
    }
 };
 constexpr int CNT_WORDS = 16;       // [0] cursor [1] hits [2] n_ext [3] error [4..8] stats of k_search (SearchArgs::stats)
+constexpr int CNT_SUMS = 192;       // behind them: 64 partial sums of k_verify, 64 + 64 of the two launches of k_verify_group; then single words
 constexpr size_t HOST_CNT_BYTES = 2048;   // the counters as read back: CNT_WORDS + 64 + 64 words, the located total, the count of big candidates
 constexpr size_t H_SMALL_BYTES = 1 << 17;      // lengths seen | phase tables of up to 256 read lengths | counters
 
@@ -386,7 +388,7 @@ extern "C" int gpumap_set_option(gpumap_ctx *ctx, const char *name, int64_t valu
    else if (!strcmp(name, "compact_results")) ctx->compact_results = value != 0;
    else if (!strcmp(name, "hit_list_guess")) { GM_FAIL_IF(value < 0, "hit_list_guess out of range."); ctx->hit_guess = value; }
    else if (!strcmp(name, "jump_bytes")) { GM_FAIL_IF(value < 0, "jump_bytes out of range."); ctx->jump_budget = value; HIP_TRY(hipSetDevice(ctx->device)); GM_FAIL_IF(gm_ctx_build_jump(ctx, -1) != 0, "cannot build the jump table."); }
-   else if (!strcmp(name, "verify")) { GM_FAIL_IF(value < -1 || value > 4 || value == 3, "verify out of range (-1, 0, 1, 2, 4)."); ctx->verify = (int)value; }
+   else if (!strcmp(name, "verify")) { GM_FAIL_IF(value != -1 && value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 16, "verify out of range (-1, 0, 1, 2, 4, 8, 16)."); ctx->verify = (int)value; }
    else if (!strcmp(name, "jump_k")) { HIP_TRY(hipSetDevice(ctx->device)); GM_FAIL_IF(gm_ctx_build_jump(ctx, (int)value) != 0, "cannot build the jump table."); }
    else if (!strcmp(name, "spill_nodes")) { GM_FAIL_IF(value < 0 || value > (1 << 22), "spill_nodes out of range."); ctx->spill_cap = value ? ((value + SPILL_CHUNK - 1) / SPILL_CHUNK) * SPILL_CHUNK : 16384; }   // (batches size their spill regions at their next run)
    else GM_FAIL("unknown option.");
@@ -587,7 +589,7 @@ extern "C" gpumap_batch *gpumap_batch_new(gpumap_ctx *ctx)
    HIP_TRY(hipEventCreateWithFlags(&b->ev_seen, hipEventDisableTiming));
    for (auto &e : b->ev) HIP_TRY(hipEventCreate(&e));
    HIP_TRY(b->seen.ensure(SEEN_BYTES));
-   HIP_TRY(b->counters.ensure(8 * (CNT_WORDS + 128 + 2)));     // counters + 64 partial sums of k_verify + 64 of k_verify_group + the count of long intervals (k_place)
+   HIP_TRY(b->counters.ensure(8 * (CNT_WORDS + CNT_SUMS + 2)));     // counters + 64 partial sums of k_verify + 64 of k_verify_group + the count of long intervals (k_place)
    return b;
 failure_return:
    gpumap_batch_free(b);
@@ -928,7 +930,7 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
       HIP_TRY(b->spill.ensure((size_t)n_waves * (size_t)ctx->spill_cap * sizeof(Node)));
       unsigned long long *cnt = b->counters.as<unsigned long long>();   // [0] cursor [1] hits [2] n_ext [3] error
       unsigned long long *host_cnt = reinterpret_cast<unsigned long long *>(b->h_small + H_SMALL_BYTES - HOST_CNT_BYTES);   // page-locked
-      constexpr size_t CNT_BYTES = 8 * (CNT_WORDS + 128);
+      constexpr size_t CNT_BYTES = 8 * (CNT_WORDS + CNT_SUMS);
       memset(host_cnt, 0, CNT_BYTES);
       // interval output needs the final interval of every hit: no short cut through the text then
       // 0: every step on the Occ table; 1: nodes of one suffix are finished on the text; 2: also nodes of two; 4: also
@@ -988,8 +990,8 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
       b->key_pos_bits = pos_bits;
       HIP_TRY(hipEventRecord(b->ev[4], st));
       const bool verified = use_verify != 0 && host_cnt[1] > 0;
-      int64_t n_stage1 = 0, n_stage2 = 0, n_iv = 0;        // keys k_verify / k_verify_group left, entries that are intervals
-      unsigned int vblocks = 0, gblocks = 0;
+      int64_t n_stage1 = 0, n_stage2[2] = {0, 0}, n_iv = 0;        // keys k_verify / the two launches of k_verify_group left, entries that are intervals
+      unsigned int vblocks = 0, gblocks[2] = {0, 0};
       if (verified) {
          const int64_t H = (int64_t)host_cnt[1];
          GM_FAIL_IF(H >= ((int64_t)1 << 31), "too many entries in the hit list (split the batch).");
@@ -1002,25 +1004,31 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
          V.key_shift = pos_bits + 4;
          const int vbd = 256;
          const bool pairs = use_verify >= 2;                             // two lanes per entry
-         const bool groups = use_verify == 4;                            // entries of three and four suffixes go to k_verify_group
+         const bool groups = use_verify >= 4;                            // entries of three and four suffixes go to k_verify_group<4>
+         const bool wides = use_verify >= 8;                             // those of five to eight (sixteen) to k_verify_group<8> (<16>)
          const dim3 vgrid((unsigned)cdiv((pairs ? 2 : 1) * V.n_list, vbd));
          vblocks = vgrid.x;
          HIP_TRY(b->vsteps.ensure(8 * (size_t)vgrid.x));
          V.n_ext = b->vsteps.as<unsigned long long>();
-         // per block: a slot of keys, a slot of interval entries, their counts (+ one word behind for the scans' totals)
+         // per block: a slot of keys, a slot of interval entries, slots of big candidates; their counts (+ one word behind each for the scan's totals)
+         const size_t nb1 = (size_t)vgrid.x + 1;
          HIP_TRY(b->stage.ensure(8 * (size_t)STAGE_PER_BLOCK * vgrid.x));
          HIP_TRY(b->iv_idx.ensure(4 * (size_t)STAGE_PER_BLOCK * vgrid.x));
-         HIP_TRY(b->blk_cnt.ensure(4 * 3 * ((size_t)vgrid.x + 1)));
-         HIP_TRY(b->blk_off.ensure(4 * 3 * ((size_t)vgrid.x + 1)));
-         HIP_TRY(hipMemsetAsync(b->blk_cnt.p, 0, 4 * 3 * ((size_t)vgrid.x + 1), st));
-         uint32_t *c_stage = b->blk_cnt.as<uint32_t>(), *c_iv = c_stage + (vgrid.x + 1), *c_big = c_iv + (vgrid.x + 1);
-         uint32_t *o_stage = b->blk_off.as<uint32_t>(), *o_iv = o_stage + (vgrid.x + 1), *o_big = o_iv + (vgrid.x + 1);
+         HIP_TRY(b->blk_cnt.ensure(4 * 4 * nb1));
+         HIP_TRY(b->blk_off.ensure(4 * 4 * nb1));
+         HIP_TRY(hipMemsetAsync(b->blk_cnt.p, 0, 4 * 4 * nb1, st));
+         uint32_t *c_stage = b->blk_cnt.as<uint32_t>(), *c_iv = c_stage + nb1, *c_big = c_iv + nb1, *c_wide = c_big + nb1;
+         uint32_t *o_stage = b->blk_off.as<uint32_t>(), *o_iv = o_stage + nb1, *o_big = o_iv + nb1, *o_wide = o_big + nb1;
          V.stage = b->stage.as<unsigned long long>(); V.stage_cnt = c_stage;
          V.iv_idx = b->iv_idx.as<uint32_t>(); V.iv_cnt = c_iv;
-         V.big_idx = nullptr; V.big_cnt = nullptr;
+         V.big_idx = nullptr; V.big_cnt = nullptr; V.wide_idx = nullptr; V.wide_cnt = nullptr;
          if (groups) {
             HIP_TRY(b->big_idx.ensure(4 * (size_t)BIG_PER_BLOCK * vgrid.x));
             V.big_idx = b->big_idx.as<uint32_t>(); V.big_cnt = c_big;
+         }
+         if (wides) {
+            HIP_TRY(b->wide_idx.ensure(4 * (size_t)BIG_PER_BLOCK * vgrid.x));
+            V.wide_idx = b->wide_idx.as<uint32_t>(); V.wide_cnt = c_wide;
          }
 #define GM_VERIFY(N) do { if (pairs) hipLaunchKernelGGL((k_verify<N, true>), vgrid, dim3(vbd), 0, st, V); \
                           else hipLaunchKernelGGL((k_verify<N, false>), vgrid, dim3(vbd), 0, st, V); } while (0)
@@ -1033,44 +1041,57 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
 #undef GM_VERIFY
          hipLaunchKernelGGL(k_sum_steps, dim3(64), dim3(256), 0, st, b->vsteps.as<const unsigned long long>(), (int64_t)vgrid.x, cnt + CNT_WORDS);
          HIP_TRY(hipGetLastError());
-         uint32_t *h_tot = reinterpret_cast<uint32_t *>(host_cnt + CNT_WORDS + 129);      // [0] keys, [1] intervals, [2] big, [3] keys of the groups
-         h_tot[0] = h_tot[1] = h_tot[2] = h_tot[3] = 0;
+         uint32_t *h_tot = reinterpret_cast<uint32_t *>(host_cnt + CNT_WORDS + CNT_SUMS + 1);   // running totals of the scan: keys, + intervals, + big, + wide; [4], [5]: keys of the groups
+         for (int k = 0; k < 6; k++) h_tot[k] = 0;
          {
             size_t tmp = 0;
-            const int items = 3 * ((int)vgrid.x + 1);           // the three count arrays lie one behind the other, each with a zero at its end:
+            const int items = 4 * (int)nb1;                     // the four count arrays lie one behind the other, each with a zero at its end:
             HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, b->blk_cnt.as<uint32_t>(), b->blk_off.as<uint32_t>(), items, st));
-            HIP_TRY(b->cub_tmp.ensure(tmp));                    // one scan; the offsets of the second and third are taken relative to their first
+            HIP_TRY(b->cub_tmp.ensure(tmp));                    // one scan; the offsets of the later ones are taken relative to their first
             HIP_TRY(hipcub::DeviceScan::ExclusiveSum(b->cub_tmp.p, tmp, b->blk_cnt.as<uint32_t>(), b->blk_off.as<uint32_t>(), items, st));
             HIP_TRY(hipMemcpyAsync(&h_tot[0], o_stage + vgrid.x, 4, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipMemcpyAsync(&h_tot[1], o_iv + vgrid.x, 4, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipMemcpyAsync(&h_tot[2], o_big + vgrid.x, 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(&h_tot[3], o_wide + vgrid.x, 4, hipMemcpyDeviceToHost, st));
          }
-         HIP_TRY(hipMemcpyAsync(host_cnt, cnt, CNT_BYTES, hipMemcpyDeviceToHost, st));
+         HIP_TRY(hipMemcpyAsync(host_cnt, cnt, 8 * (CNT_WORDS + 64), hipMemcpyDeviceToHost, st));
          GM_SYNC(b, st);
          n_stage1 = h_tot[0];
          n_iv = (int64_t)h_tot[1] - (int64_t)h_tot[0];
-         const int64_t n_big = (int64_t)h_tot[2] - (int64_t)h_tot[1];
+         const int64_t n_class[2] = {(int64_t)h_tot[2] - (int64_t)h_tot[1], (int64_t)h_tot[3] - (int64_t)h_tot[2]};
          if (n_iv > 0) {
             HIP_TRY(b->iv_dense.ensure(4 * (size_t)n_iv));
             hipLaunchKernelGGL(k_list_compact, vgrid, dim3(STAGE_PER_BLOCK), 0, st, b->iv_idx.as<const uint32_t>(), (const uint32_t *)c_iv,
                                (const uint32_t *)o_iv, STAGE_PER_BLOCK, b->iv_dense.as<uint32_t>() - h_tot[0]);
          }
-         if (n_big > 0) {
-            constexpr int G = 4;
-            HIP_TRY(b->big_dense.ensure(4 * (size_t)n_big));
-            hipLaunchKernelGGL(k_list_compact, vgrid, dim3(BIG_PER_BLOCK), 0, st, b->big_idx.as<const uint32_t>(), (const uint32_t *)c_big,
-                               (const uint32_t *)o_big, BIG_PER_BLOCK, b->big_dense.as<uint32_t>() - h_tot[1]);
-            const dim3 ggrid((unsigned)cdiv(G * n_big, vbd));
-            gblocks = ggrid.x;
-            HIP_TRY(b->vsteps2.ensure(8 * (size_t)ggrid.x));
-            HIP_TRY(b->stage2.ensure(8 * (size_t)STAGE_PER_BLOCK * ggrid.x));
-            HIP_TRY(b->blk_cnt2.ensure(4 * ((size_t)ggrid.x + 1)));
-            HIP_TRY(b->blk_off2.ensure(4 * ((size_t)ggrid.x + 1)));
-            HIP_TRY(hipMemsetAsync(b->blk_cnt2.p, 0, 4 * ((size_t)ggrid.x + 1), st));
+         // the two classes of big candidates: a dense list each, then k_verify_group with 4 / 16 lanes per entry
+         bool any_group = false;
+         for (int c = 0; c < 2; c++) {
+            const int64_t n_big = n_class[c];
+            n_stage2[c] = 0; gblocks[c] = 0;
+            if (n_big <= 0) continue;
+            any_group = true;
+            const int G = c == 0 ? 4 : use_verify;
+            DevBuf &dense_buf = c == 0 ? b->big_dense : b->wide_dense;
+            HIP_TRY(dense_buf.ensure(4 * (size_t)n_big));
+            hipLaunchKernelGGL(k_list_compact, vgrid, dim3(BIG_PER_BLOCK), 0, st, (c == 0 ? b->big_idx : b->wide_idx).as<const uint32_t>(),
+                               (const uint32_t *)(c == 0 ? c_big : c_wide), (const uint32_t *)(c == 0 ? o_big : o_wide), BIG_PER_BLOCK,
+                               dense_buf.as<uint32_t>() - h_tot[1 + c]);
+            const dim3 ggrid((unsigned)cdiv((int64_t)G * n_big, vbd));
+            gblocks[c] = ggrid.x;
+            HIP_TRY(b->vsteps2[c].ensure(8 * (size_t)ggrid.x));
+            HIP_TRY(b->stage2[c].ensure(8 * (size_t)STAGE_PER_BLOCK * ggrid.x));
+            HIP_TRY(b->blk_cnt2[c].ensure(4 * ((size_t)ggrid.x + 1)));
+            HIP_TRY(b->blk_off2[c].ensure(4 * ((size_t)ggrid.x + 1)));
+            HIP_TRY(hipMemsetAsync(b->blk_cnt2[c].p, 0, 4 * ((size_t)ggrid.x + 1), st));
             VerifyArgs V2 = V;
-            V2.stage = b->stage2.as<unsigned long long>(); V2.stage_cnt = b->blk_cnt2.as<uint32_t>();
-#define GM_GROUP(N) hipLaunchKernelGGL((k_verify_group<N, G>), ggrid, dim3(vbd), 0, st, V2, b->big_dense.as<const uint32_t>(), n_big, \
-                                       b->vsteps2.as<unsigned long long>())
+            V2.stage = b->stage2[c].as<unsigned long long>(); V2.stage_cnt = b->blk_cnt2[c].as<uint32_t>();
+#define GM_GROUP(N) do { if (c == 0) hipLaunchKernelGGL((k_verify_group<N, 4>), ggrid, dim3(vbd), 0, st, V2, dense_buf.as<const uint32_t>(), n_big, \
+                                                          b->vsteps2[c].as<unsigned long long>()); \
+                         else if (G == 8) hipLaunchKernelGGL((k_verify_group<N, 8>), ggrid, dim3(vbd), 0, st, V2, dense_buf.as<const uint32_t>(), n_big, \
+                                                 b->vsteps2[c].as<unsigned long long>()); \
+                         else hipLaunchKernelGGL((k_verify_group<N, 16>), ggrid, dim3(vbd), 0, st, V2, dense_buf.as<const uint32_t>(), n_big, \
+                                                 b->vsteps2[c].as<unsigned long long>()); } while (0)
             switch (cdiv(b->maxlen, 64)) {
                case 1:  GM_GROUP(1); break;
                case 2:  GM_GROUP(2); break;
@@ -1078,22 +1099,25 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
                default: GM_GROUP(4); break;
             }
 #undef GM_GROUP
-            hipLaunchKernelGGL(k_sum_steps, dim3(64), dim3(256), 0, st, b->vsteps2.as<const unsigned long long>(), (int64_t)ggrid.x, cnt + CNT_WORDS + 64);
+            hipLaunchKernelGGL(k_sum_steps, dim3(64), dim3(256), 0, st, b->vsteps2[c].as<const unsigned long long>(), (int64_t)ggrid.x,
+                               cnt + CNT_WORDS + 64 * (1 + c));
             HIP_TRY(hipGetLastError());
             size_t tmp = 0;
-            HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, b->blk_cnt2.as<uint32_t>(), b->blk_off2.as<uint32_t>(), (int)ggrid.x + 1, st));
+            HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, b->blk_cnt2[c].as<uint32_t>(), b->blk_off2[c].as<uint32_t>(), (int)ggrid.x + 1, st));
             HIP_TRY(b->cub_tmp.ensure(tmp));
-            HIP_TRY(hipcub::DeviceScan::ExclusiveSum(b->cub_tmp.p, tmp, b->blk_cnt2.as<uint32_t>(), b->blk_off2.as<uint32_t>(), (int)ggrid.x + 1, st));
-            HIP_TRY(hipMemcpyAsync(&h_tot[3], b->blk_off2.as<uint32_t>() + ggrid.x, 4, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(host_cnt + CNT_WORDS + 64, cnt + CNT_WORDS + 64, 8 * 64, hipMemcpyDeviceToHost, st));
-            GM_SYNC(b, st);
-            n_stage2 = h_tot[3];
+            HIP_TRY(hipcub::DeviceScan::ExclusiveSum(b->cub_tmp.p, tmp, b->blk_cnt2[c].as<uint32_t>(), b->blk_off2[c].as<uint32_t>(), (int)ggrid.x + 1, st));
+            HIP_TRY(hipMemcpyAsync(&h_tot[4 + c], b->blk_off2[c].as<uint32_t>() + ggrid.x, 4, hipMemcpyDeviceToHost, st));
          }
-         for (int k = 0; k < (n_big > 0 ? 128 : 64); k++) {
+         if (any_group) {
+            HIP_TRY(hipMemcpyAsync(host_cnt + CNT_WORDS + 64, cnt + CNT_WORDS + 64, 8 * 128, hipMemcpyDeviceToHost, st));
+            GM_SYNC(b, st);
+            n_stage2[0] = h_tot[4]; n_stage2[1] = h_tot[5];
+         }
+         for (int k = 0; k < (any_group ? CNT_SUMS : 64); k++) {
             const unsigned long long st_k = host_cnt[CNT_WORDS + k] & 0xffffffffull;
             host_cnt[2] += st_k; verify_steps += st_k; verify_windows += host_cnt[CNT_WORDS + k] >> 32;
          }
-         b->n_big = n_big;
+         b->n_big = n_class[0] + n_class[1];
       }
       HIP_TRY(hipEventRecord(b->ev[1], st));
       b->n_hits = (int64_t)host_cnt[1];            // entries of the list, holes included
@@ -1128,12 +1152,12 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
          HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, b->hit_sizes.as<int64_t>(), b->hit_off.as<int64_t>(), (int)(n_look + 1), st));
          HIP_TRY(b->cub_tmp.ensure(tmp));
          HIP_TRY(hipcub::DeviceScan::ExclusiveSum(b->cub_tmp.p, tmp, b->hit_sizes.as<int64_t>(), b->hit_off.as<int64_t>(), (int)(n_look + 1), st));
-         int64_t *h_L = reinterpret_cast<int64_t *>(host_cnt + CNT_WORDS + 128);
+         int64_t *h_L = reinterpret_cast<int64_t *>(host_cnt + CNT_WORDS + CNT_SUMS);
          HIP_TRY(hipMemcpyAsync(h_L, b->hit_off.as<int64_t>() + n_look, 8, hipMemcpyDeviceToHost, st));
          GM_SYNC(b, st);
          L_iv = *h_L;
       }
-      const int64_t L = n_stage1 + n_stage2 + L_iv;
+      const int64_t L = n_stage1 + n_stage2[0] + n_stage2[1] + L_iv;
       b->n_locs = L;
       if (L > 0) {
          GM_FAIL_IF(L >= ((int64_t)1 << 31), "too many located hits in one batch (split the batch).");
@@ -1142,14 +1166,16 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
          if (n_stage1 > 0)
             hipLaunchKernelGGL(k_stage_compact, dim3(vblocks), dim3(STAGE_PER_BLOCK), 0, st, b->stage.as<const unsigned long long>(),
                                b->blk_cnt.as<const uint32_t>(), b->blk_off.as<const uint32_t>(), b->keys.as<unsigned long long>());
-         if (n_stage2 > 0)
-            hipLaunchKernelGGL(k_stage_compact, dim3(gblocks), dim3(STAGE_PER_BLOCK), 0, st, b->stage2.as<const unsigned long long>(),
-                               b->blk_cnt2.as<const uint32_t>(), b->blk_off2.as<const uint32_t>(), b->keys.as<unsigned long long>() + n_stage1);
+         for (int c = 0; c < 2; c++)
+            if (n_stage2[c] > 0)
+               hipLaunchKernelGGL(k_stage_compact, dim3(gblocks[c]), dim3(STAGE_PER_BLOCK), 0, st, b->stage2[c].as<const unsigned long long>(),
+                                  b->blk_cnt2[c].as<const uint32_t>(), b->blk_off2[c].as<const uint32_t>(),
+                                  b->keys.as<unsigned long long>() + n_stage1 + (c == 1 ? n_stage2[0] : 0));
          if (L_iv > 0) {
-            unsigned long long *keys_iv = b->keys.as<unsigned long long>() + n_stage1 + n_stage2;
+            unsigned long long *keys_iv = b->keys.as<unsigned long long>() + n_stage1 + n_stage2[0] + n_stage2[1];
             const unsigned int longer_cap = (unsigned int)(L_iv / PLACE_INLINE + 1);
             HIP_TRY(b->longer.ensure(4 * (size_t)longer_cap));
-            unsigned int *n_longer = (unsigned int *)(cnt + CNT_WORDS + 128);
+            unsigned int *n_longer = (unsigned int *)(cnt + CNT_WORDS + CNT_SUMS);
             HIP_TRY(hipMemsetAsync(n_longer, 0, 8, st));
             hipLaunchKernelGGL(k_place, dim3((unsigned)cdiv(n_look, 256)), dim3(256), 0, st, ctx->ix, b->hits.as<const Node>(), dense, n_look,
                                b->hit_sizes.as<const int64_t>(), b->hit_off.as<const int64_t>(), pos_bits, keys_iv,

@@ -439,7 +439,8 @@ struct VerifyArgs {
    unsigned long long *stage;
    uint32_t *stage_cnt;
    uint32_t *iv_idx, *iv_cnt;
-   uint32_t *big_idx, *big_cnt;    // (nullptr: there are none)
+   uint32_t *big_idx, *big_cnt;    // candidates of 3 .. 4 suffixes (nullptr: there are none)
+   uint32_t *wide_idx, *wide_cnt;  // candidates of 5 .. 16 suffixes (nullptr: there are none)
 };
 constexpr int STAGE_PER_BLOCK = 256;     // keys a block of 256 lanes can produce (one per lane)
 
@@ -724,7 +725,7 @@ __global__ void __launch_bounds__(256) k_verify(VerifyArgs A)
    const int q = PAIRS ? (int)(th & 1) : 0;
    uint32_t steps = 0;                 // this walk's steps (0 for a lane without a suffix)
    unsigned long long key = ~0ull;
-   bool cand = false, pair = false, big = false;
+   bool cand = false, pair = false, big = false, wide = false;
    int64_t p0 = 0;
    uint32_t read = 0;
    int row = 0;
@@ -753,7 +754,8 @@ __global__ void __launch_bounds__(256) k_verify(VerifyArgs A)
    if (cand) {
       Node nd = A.list[i];
       pair = PAIRS && nd.w[2] == 2;
-      big = PAIRS && nd.w[2] > 2;
+      wide = PAIRS && nd.w[2] > 4;
+      big = PAIRS && nd.w[2] > 2;                 // (the wide ones included: neither is replayed here)
       mine = !big && (q == 0 || pair);
    }
    if (mine) {
@@ -801,23 +803,30 @@ __global__ void __launch_bounds__(256) k_verify(VerifyArgs A)
    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
    const unsigned long long lt = (1ull << lane) - 1ull;
    const bool found = cand && !big && key != ~0ull;
-   const unsigned long long foundm = __ballot(found), ivm = __ballot(interval), bigm = __ballot(big && q == 0);
-   __shared__ uint32_t s_cnt[3][4];
-   if (lane == 0) { s_cnt[0][w] = (uint32_t)__popcll(foundm); s_cnt[1][w] = (uint32_t)__popcll(ivm); s_cnt[2][w] = (uint32_t)__popcll(bigm); }
+   const unsigned long long foundm = __ballot(found), ivm = __ballot(interval), bigm = __ballot(big && !wide && q == 0),
+                            widem = __ballot(wide && q == 0);
+   __shared__ uint32_t s_cnt[4][4];
+   if (lane == 0) {
+      s_cnt[0][w] = (uint32_t)__popcll(foundm); s_cnt[1][w] = (uint32_t)__popcll(ivm);
+      s_cnt[2][w] = (uint32_t)__popcll(bigm); s_cnt[3][w] = (uint32_t)__popcll(widem);
+   }
    verify_block_sums(steps, mine, A.n_ext);         // (barrier inside)
-   uint32_t off[3] = {0, 0, 0}, total[3] = {0, 0, 0};
+   uint32_t off[4] = {0, 0, 0, 0}, total[4] = {0, 0, 0, 0};
 #pragma unroll
    for (int k = 0; k < 4; k++)
 #pragma unroll
-      for (int t = 0; t < 3; t++) { if (k < w) off[t] += s_cnt[t][k]; total[t] += s_cnt[t][k]; }
+      for (int t = 0; t < 4; t++) { if (k < w) off[t] += s_cnt[t][k]; total[t] += s_cnt[t][k]; }
    if (found) A.stage[(size_t)blockIdx.x * STAGE_PER_BLOCK + off[0] + (uint32_t)__popcll(foundm & lt)] = key;
    if (interval) A.iv_idx[(size_t)blockIdx.x * STAGE_PER_BLOCK + off[1] + (uint32_t)__popcll(ivm & lt)] = (uint32_t)i;
-   if (PAIRS && A.big_idx != nullptr && big && q == 0)
+   if (PAIRS && A.big_idx != nullptr && big && !wide && q == 0)
       A.big_idx[(size_t)blockIdx.x * BIG_PER_BLOCK + off[2] + (uint32_t)__popcll(bigm & lt)] = (uint32_t)i;
+   if (PAIRS && A.wide_idx != nullptr && wide && q == 0)
+      A.wide_idx[(size_t)blockIdx.x * BIG_PER_BLOCK + off[3] + (uint32_t)__popcll(widem & lt)] = (uint32_t)i;
    if (threadIdx.x == 0) {
       A.stage_cnt[blockIdx.x] = total[0];
       A.iv_cnt[blockIdx.x] = total[1];
       if (PAIRS && A.big_idx != nullptr) A.big_cnt[blockIdx.x] = total[2];
+      if (PAIRS && A.wide_idx != nullptr) A.wide_cnt[blockIdx.x] = total[3];
    }
 }
 
@@ -839,6 +848,12 @@ __global__ void k_list_compact(const uint32_t *idx, const uint32_t *cnt, const u
 // of those paths: walk q adds its own steps minus the most it shares with any walk before it (two paths share
 // their nodes up to and including the first position where their texts differ: verify_walked).  The keys of the hits
 // go to the block's slot of the staging area (A.stage, A.stage_cnt: those of this launch), as in k_verify.
+__device__ __forceinline__ int __reduce_max_csz(int v)
+{
+   for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+   return v;
+}
+
 template <int NCH, int G>
 __global__ void __launch_bounds__(256) k_verify_group(VerifyArgs A, const uint32_t *dense, int64_t n_big, unsigned long long *n_ext_out)
 {
@@ -869,13 +884,14 @@ __global__ void __launch_bounds__(256) k_verify_group(VerifyArgs A, const uint32
       verify_replay<NCH, KEEP_PLANES>(A, nd, q, E, S, QN, tw, planes, steps, key, p0, read, row, phase0, pos0, end0, fw0);
    }
    uint32_t best = 0;
-#pragma unroll
-   for (int j = 0; j < G - 1; j++) {              // every lane takes part in the exchanges
-      const int src = base + j;
-      const uint32_t steps_o = (uint32_t)__shfl((int)steps, src);
-      uint32_t wk = 0;
-      if (KEEP_PLANES) {
-         // every walk holds its window's planes (the letter-by-letter path fills them too): where the two windows differ
+   if (KEEP_PLANES) {
+      // Every walk holds its window's planes (the letter-by-letter path fills them too).  Copies of a repeat mostly spell
+      // the same letters over the whole read: a walk whose window equals that of the lane before is the same path of
+      // the search tree and adds nothing; only the first walk of each distinct window (a representative) is compared
+      // with the representatives before it.  Every lane takes part in the exchanges.
+      const int m = mine ? (int)A.row_len[row] : 0;
+      uint64_t TD[NCH];
+      auto differ = [&](int src) {
          uint32_t dw[2 * NCH];
 #pragma unroll
          for (int w = 0; w < 2 * NCH; w++) {
@@ -883,18 +899,49 @@ __global__ void __launch_bounds__(256) k_verify_group(VerifyArgs A, const uint32
 #pragma unroll
             for (int p = 0; p < 3; p++) dw[w] |= tw[p][w] ^ (uint32_t)__shfl((int)tw[p][w], src);
          }
-         uint64_t TD[NCH];
 #pragma unroll
          for (int c = 0; c < NCH; c++) TD[c] = (uint64_t)dw[2 * c] | ((uint64_t)dw[2 * c + 1] << 32);
-         if (mine && q > j) wk = verify_walked_td<NCH>(A, TD, row, phase0, pos0, end0, fw0);
-      } else {
+      };
+      differ(lane > 0 ? lane - 1 : 0);
+      bool dup = false;
+      if (mine && q > 0) {
+         uint64_t any = 0;
+#pragma unroll
+         for (int c = 0; c < NCH; c++) {
+            const int hi = m - 64 * c;
+            any |= TD[c] & (hi >= 64 ? ~0ull : hi > 0 ? (1ull << hi) - 1ull : 0ull);
+         }
+         dup = any == 0;
+      }
+      if (dup) best = steps;
+      const bool rep = mine && !dup;
+      const uint32_t reps = (uint32_t)((__ballot(rep) >> base) & ((1ull << G) - 1ull));
+      uint32_t todo = (rep && q > 0) ? (reps & ((1u << q) - 1u)) : 0u;
+      while (__any(todo != 0)) {
+         const int src = todo ? base + (__ffs((int)todo) - 1) : lane;
+         const uint32_t steps_o = (uint32_t)__shfl((int)steps, src);
+         differ(src);
+         if (todo) {
+            const uint32_t wk = verify_walked_td<NCH>(A, TD, row, phase0, pos0, end0, fw0);
+            best = max(best, min(wk, min(steps, steps_o)));
+            todo &= todo - 1;
+         }
+      }
+   } else {
+      const int rounds = __reduce_max_csz(csz) - 1;      // (wave-uniform: the most suffixes any entry of the wave holds)
+#pragma unroll 1
+      for (int j = 0; j < rounds; j++) {             // every lane takes part in the exchanges
+         const int src = base + j;
+         const uint32_t steps_o = (uint32_t)__shfl((int)steps, src);
          uint64_t Eo[NCH], TD[NCH];
 #pragma unroll
          for (int c = 0; c < NCH; c++) { Eo[c] = __shfl(E[c], src); TD[c] = 0; }
          const int64_t p0_o = __shfl(p0, src);
-         if (mine && q > j) wk = verify_walked<NCH>(A, E, Eo, QN, TD, false, p0, p0_o, row, phase0, pos0, end0, fw0);
+         if (mine && q > j) {
+            const uint32_t wk = verify_walked<NCH>(A, E, Eo, QN, TD, false, p0, p0_o, row, phase0, pos0, end0, fw0);
+            best = max(best, min(wk, min(steps, steps_o)));
+         }
       }
-      if (mine && q > j) best = max(best, min(wk, min(steps, steps_o)));
    }
    steps -= best;
    const bool found = valid && key != ~0ull;

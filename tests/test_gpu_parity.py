@@ -131,7 +131,7 @@ def test_verify_path_matches_reference_dump(workdir, name, tau):
     codes, offs = common.encode_reads(reads)
     ref = po.HitDump.load(os.path.join(common.GOLDEN, "%s.tau%d.bin" % (name, tau)))
     want_ext = orc.map_batch(codes, offs, tau, threads=2).n_ext
-    for verify in (4, 2, 1, 0):                  # nodes of up to four / of one or two suffixes / of one suffix / none finished on the text
+    for verify in (16, 4, 2, 1, 0):                  # nodes of up to four / of one or two suffixes / of one suffix / none finished on the text
         ctx.set_option("verify", verify)
         b = ctx.upload(codes, offs)
         c = b.run(tau)
@@ -174,7 +174,7 @@ def test_verify_at_the_ends_of_the_text_and_at_separators(workdir):
     offs = np.concatenate(([0], np.cumsum([len(r) for r in reads]))).astype(np.int64)
     for tau in (0, 1, 2, 3):
         d = orc.map_batch(codes, offs, tau, threads=2)
-        for verify in (4, 2, 1, 0):
+        for verify in (16, 4, 2, 1, 0):
             ctx.set_option("verify", verify)
             h = ctx.map_batch(codes, offs, tau)
             assert np.array_equal(h.status, d.status)
@@ -295,7 +295,7 @@ def test_located_only_paths_match_oracle_on_repeats(workdir, m, tau):
     codes, offs = synth.make_reads(seqs, 4000 if tau <= 4 else 300, m, min(tau, 4), seed=300 + m, n_frac=0.02)
     ctx = ma.Context.from_files(base, 0)
     d = po.Index(base).map_batch(codes.reshape(-1), offs, tau, threads=8)
-    for verify in (4, 2, 1):
+    for verify in (16, 4, 2, 1):
         ctx.set_option("verify", verify)
         h = ctx.map_batch(codes.reshape(-1), offs, tau)
         assert np.array_equal(h.located(), d.located())
@@ -323,7 +323,7 @@ def test_pairs_on_a_duplicated_text(workdir, div):
     orc = po.Index(base)
     for tau in (2, 3):
         d = orc.map_batch(codes.reshape(-1), offs, tau, threads=8)
-        for verify in (4, 2, 1, 0):
+        for verify in (16, 4, 2, 1, 0):
             ctx.set_option("verify", verify)
             b_ = ctx.upload(codes.reshape(-1), offs)
             c = b_.run(tau)
@@ -335,12 +335,13 @@ def test_pairs_on_a_duplicated_text(workdir, div):
     ctx.close()
 
 
-@pytest.mark.parametrize("copies,div", [(3, 0.0), (3, 0.02), (4, 0.01), (4, 0.06), (6, 0.03)])
+@pytest.mark.parametrize("copies,div", [(3, 0.0), (3, 0.02), (4, 0.01), (4, 0.06), (6, 0.03), (8, 0.02), (12, 0.01), (16, 0.0), (20, 0.01)])
 def test_groups_on_a_text_of_several_copies(workdir, copies, div):
-    """Three to six copies of one sequence, each with its own substitutions (and an N run in one): the nodes of the
-    search hold three and four suffixes for long stretches and the copies part one after the other.  With verify = 4
-    such nodes are finished by k_verify_group, four lanes per node: the oracle's located hits, and its count of
-    extension steps (the walks of one node are counted as the union of their paths in the reference's search tree)."""
+    """Three to twenty copies of one sequence, each with its own substitutions (and an N run in one): the nodes of the
+    search hold several suffixes for long stretches and the copies part one after the other.  With verify = 4 the nodes
+    of three and four suffixes are finished by k_verify_group, four lanes per node; with verify = 16 also those of five
+    to sixteen, sixteen lanes per node: the oracle's located hits, and its count of extension steps (the walks of one
+    node are counted as the union of their paths in the reference's search tree)."""
     rng = np.random.default_rng(int(div * 1000) + 11 * copies)
     a = rng.integers(0, 4, 60_000).astype(np.uint8)
     seqs = []
@@ -358,7 +359,7 @@ def test_groups_on_a_text_of_several_copies(workdir, copies, div):
     for m, tau in ((100, 2), (150, 4), (70, 3)):
         codes, offs = synth.make_reads(seqs, 2500, m, tau, seed=copies * 100 + m, n_frac=0.02)
         d = orc.map_batch(codes.reshape(-1), offs, tau, threads=8)
-        for verify in (4, 2):
+        for verify in (16, 8, 4, 2):
             ctx.set_option("verify", verify)
             b_ = ctx.upload(codes.reshape(-1), offs)
             b_.run(tau)
@@ -367,7 +368,7 @@ def test_groups_on_a_text_of_several_copies(workdir, copies, div):
             b_.close()
             assert np.array_equal(h.located(), d.located()), (m, tau, verify)
             assert h.n_ext == d.n_ext, (m, tau, verify)
-            assert (big > 0) == (verify == 4 and copies <= 4 or (verify == 4 and big > 0))
+            assert big == 0 if verify == 2 else (big > 0 or not (verify == 16 and copies <= 16 or verify == 8 and copies <= 8)), (m, tau, verify, big)
         assert big >= 0
     ctx.close()
 
