@@ -226,18 +226,22 @@ def main():
     pipe = ctx.pipe(depth=args.depth, tau=w["tau"], flags=ma.SRC_TEXT | ma.SRC_DEVICE | ma.PIPE_COMPACT)
     n_reads = w["reads"]
 
+    done_at = []                                # when each chunk's result came back (the spread of the steps goes into the line)
+
     def run_steps(k_steps, first=0):
         located = 0
         taken = 0
         for k in range(k_steps):
             if k - taken == args.depth:
                 raw, _ = pipe.next_raw()
+                done_at.append(time.perf_counter())
                 located += int(raw.n_locs)
                 pipe.release_raw(raw)
                 taken += 1
             pipe.submit(d_chunks[(first + k) % len(d_chunks)].data_ptr(), d_offs.data_ptr(), n_reads)
         while taken < k_steps:
             raw, _ = pipe.next_raw()
+            done_at.append(time.perf_counter())
             located += int(raw.n_locs)
             pipe.release_raw(raw)
             taken += 1
@@ -246,6 +250,7 @@ def main():
     run_steps(args.depth)                       # every slot allocates its device buffers and its result arena (set-up)
     run_steps(args.warmup)
     barrier()
+    del done_at[:]
     t0 = time.perf_counter()
     located_total = run_steps(args.steps, first=args.warmup)
     barrier()
@@ -341,6 +346,7 @@ def main():
                                        "chunks pipelined over %d batch objects (gpumap_pipe)" % args.depth,
                        "parallelism": "reads sharded over %d GPU(s), index replicated (RCCL broadcast)" % world},
             "located_per_step": located_total / args.steps,
+            "step_intervals_ms": [round(1e3 * (b_ - a_), 2) for a_, b_ in zip([t0] + done_at[:-1], done_at)],
             "device_resident": {"reads_per_s": n_reads / (mean["device_total"] * 1e-3), "ms_per_chunk": mean["device_total"],
                                 "note": "one chunk at a time on one batch object, results left in HBM (no D2H, no overlap): "
                                         "encode + search + locate + order; round 1's headline was this without the encoding"},

@@ -27,6 +27,8 @@ struct Slot {
    void *user = nullptr;
    gpumap_hits hits;
    int rc = 0;
+   int ctx_index = 0;            // which of the pipe's contexts the slot works on
+   uint64_t run_seq = 0;         // its chunk's place among the chunks of that context
 };
 }  // namespace
 
@@ -35,6 +37,12 @@ struct gpumap_pipe {
    int tau = 0, src_flags = 0, result_flags = 0;
    uint64_t submitted = 0, returned = 0;
    bool closed = false, stop = false;
+   // The runs of the chunks of one context take turns, in submit order: the kernels of a chunk are enqueued stage by
+   // stage (the host reads counts in between), and with several chunks in their run at once the stages interleave on the
+   // context's kernel stream: every chunk then takes as long as all of them together, in lock-step (results came back in
+   // bursts of `depth`, the first after 58 ms instead of 18).  Uploads and result copies still overlap the runs.
+   std::vector<uint64_t> ctx_submitted, ctx_turn;
+   bool ordered = true;
    std::mutex m;
    std::condition_variable cv;
 };
@@ -53,7 +61,15 @@ static void pipe_worker(gpumap_pipe *p, Slot *s)
       if (dbg) fprintf(stderr, "[pipe] slot %d: fill %ld reads\n", id, (long)s->n_reads);
       int rc = gm_batch_fill(s->ctx, s->batch, s->src, s->offsets, s->n_reads, p->src_flags, false);
       if (dbg) fprintf(stderr, "[pipe] slot %d: run (rc %d)\n", id, rc);
+      if (p->ordered) {
+         std::unique_lock<std::mutex> l(p->m);
+         p->cv.wait(l, [&] { return p->ctx_turn[(size_t)s->ctx_index] == s->run_seq; });
+      }
       if (rc == 0) rc = gm_batch_run(s->ctx, s->batch, p->tau, 0, p->result_flags);
+      if (p->ordered) {
+         { std::lock_guard<std::mutex> l(p->m); p->ctx_turn[(size_t)s->ctx_index]++; }
+         p->cv.notify_all();
+      }
       if (dbg) fprintf(stderr, "[pipe] slot %d: fetch (rc %d)\n", id, rc);
       if (rc == 0) rc = gm_batch_fetch(s->ctx, s->batch, &s->hits, p->result_flags);
       if (dbg) fprintf(stderr, "[pipe] slot %d: done (rc %d)\n", id, rc);
@@ -97,9 +113,13 @@ extern "C" gpumap_pipe *gpumap_pipe_create(gpumap_ctx *const *ctxs, int n_ctx, i
    p->src_flags = flags & (GPUMAP_SRC_TEXT | GPUMAP_SRC_DEVICE);
    p->result_flags = GM_RESULT_PINNED | GM_RESULT_ONE_ARENA | ((flags & GPUMAP_PIPE_COMPACT) ? GM_RESULT_COMPACT : 0);
    p->slots = std::vector<Slot>((size_t)depth * (size_t)n_ctx);
+   p->ctx_submitted.assign((size_t)n_ctx, 0);
+   p->ctx_turn.assign((size_t)n_ctx, 0);
+   p->ordered = !getenv("GPUMAP_PIPE_ORDERED") || atoi(getenv("GPUMAP_PIPE_ORDERED")) != 0;      // (0: tuning aid, the runs interleave)
    for (size_t i = 0; i < p->slots.size(); i++) {
       Slot &s = p->slots[i];
       s.ctx = ctxs[i % (size_t)n_ctx];                   // consecutive chunks go to different GPUs
+      s.ctx_index = (int)(i % (size_t)n_ctx);
       s.batch = gpumap_batch_new(s.ctx);
       GM_FAIL_IF(s.batch == nullptr, "cannot create a batch.");
       void *run = nullptr, *copy = nullptr, *up = nullptr;
@@ -123,6 +143,7 @@ extern "C" int gpumap_pipe_submit(gpumap_pipe *p, const void *src, const int64_t
       Slot &s = p->slots[p->submitted % p->slots.size()];
       p->cv.wait(l, [&] { return s.state == SLOT_FREE; });
       s.src = src; s.offsets = offsets; s.n_reads = n_reads; s.user = user;
+      s.run_seq = p->ctx_submitted[(size_t)s.ctx_index]++;
       s.state = SLOT_QUEUED;
       p->submitted++;
    }
