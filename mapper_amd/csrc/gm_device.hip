@@ -389,6 +389,7 @@ extern "C" int gpumap_set_option(gpumap_ctx *ctx, const char *name, int64_t valu
    else if (!strcmp(name, "hit_list_guess")) { GM_FAIL_IF(value < 0, "hit_list_guess out of range."); ctx->hit_guess = value; }
    else if (!strcmp(name, "jump_bytes")) { GM_FAIL_IF(value < 0, "jump_bytes out of range."); ctx->jump_budget = value; HIP_TRY(hipSetDevice(ctx->device)); GM_FAIL_IF(gm_ctx_build_jump(ctx, -1) != 0, "cannot build the jump table."); }
    else if (!strcmp(name, "verify")) { GM_FAIL_IF(value != -1 && value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 16, "verify out of range (-1, 0, 1, 2, 4, 8, 16)."); ctx->verify = (int)value; }
+   else if (!strcmp(name, "verify_tile")) { GM_FAIL_IF(value < 0 || value > VERIFY_TILE_MAX, "verify_tile out of range (0 = default, at most 1024)."); ctx->verify_tile = (int)value; }
    else if (!strcmp(name, "jump_k")) { HIP_TRY(hipSetDevice(ctx->device)); GM_FAIL_IF(gm_ctx_build_jump(ctx, (int)value) != 0, "cannot build the jump table."); }
    else if (!strcmp(name, "spill_nodes")) { GM_FAIL_IF(value < 0 || value > (1 << 22), "spill_nodes out of range."); ctx->spill_cap = value ? ((value + SPILL_CHUNK - 1) / SPILL_CHUNK) * SPILL_CHUNK : 16384; }   // (batches size their spill regions at their next run)
    else GM_FAIL("unknown option.");
@@ -992,6 +993,7 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
       const bool verified = use_verify != 0 && host_cnt[1] > 0;
       int64_t n_stage1 = 0, n_stage2[2] = {0, 0}, n_iv = 0;        // keys k_verify / the two launches of k_verify_group left, entries that are intervals
       unsigned int vblocks = 0, gblocks[2] = {0, 0};
+      int vstage_per = 0;
       if (verified) {
          const int64_t H = (int64_t)host_cnt[1];
          GM_FAIL_IF(H >= ((int64_t)1 << 31), "too many entries in the hit list (split the batch).");
@@ -1006,14 +1008,17 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
          const bool pairs = use_verify >= 2;                             // two lanes per entry
          const bool groups = use_verify >= 4;                            // entries of three and four suffixes go to k_verify_group<4>
          const bool wides = use_verify >= 8;                             // those of five to eight (sixteen) to k_verify_group<8> (<16>)
-         const dim3 vgrid((unsigned)cdiv((pairs ? 2 : 1) * V.n_list, vbd));
-         vblocks = vgrid.x;
+         // entries a block takes: with pairs about 1.4 suffixes to replay per entry: rounds of 256 lanes, only the last one of a block partly filled
+         const int vtile = ctx->verify_tile > 0 ? ctx->verify_tile : 512;
+         V.tile = vtile; V.stage_per = pairs ? 2 * vtile : vtile;
+         const dim3 vgrid((unsigned)cdiv(V.n_list, vtile));
+         vblocks = vgrid.x; vstage_per = V.stage_per;
          HIP_TRY(b->vsteps.ensure(8 * (size_t)vgrid.x));
          V.n_ext = b->vsteps.as<unsigned long long>();
          // per block: a slot of keys, a slot of interval entries, slots of big candidates; their counts (+ one word behind each for the scan's totals)
          const size_t nb1 = (size_t)vgrid.x + 1;
-         HIP_TRY(b->stage.ensure(8 * (size_t)STAGE_PER_BLOCK * vgrid.x));
-         HIP_TRY(b->iv_idx.ensure(4 * (size_t)STAGE_PER_BLOCK * vgrid.x));
+         HIP_TRY(b->stage.ensure(8 * (size_t)V.stage_per * vgrid.x));
+         HIP_TRY(b->iv_idx.ensure(4 * (size_t)vtile * vgrid.x));
          HIP_TRY(b->blk_cnt.ensure(4 * 4 * nb1));
          HIP_TRY(b->blk_off.ensure(4 * 4 * nb1));
          HIP_TRY(hipMemsetAsync(b->blk_cnt.p, 0, 4 * 4 * nb1, st));
@@ -1023,11 +1028,11 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
          V.iv_idx = b->iv_idx.as<uint32_t>(); V.iv_cnt = c_iv;
          V.big_idx = nullptr; V.big_cnt = nullptr; V.wide_idx = nullptr; V.wide_cnt = nullptr;
          if (groups) {
-            HIP_TRY(b->big_idx.ensure(4 * (size_t)BIG_PER_BLOCK * vgrid.x));
+            HIP_TRY(b->big_idx.ensure(4 * (size_t)vtile * vgrid.x));
             V.big_idx = b->big_idx.as<uint32_t>(); V.big_cnt = c_big;
          }
          if (wides) {
-            HIP_TRY(b->wide_idx.ensure(4 * (size_t)BIG_PER_BLOCK * vgrid.x));
+            HIP_TRY(b->wide_idx.ensure(4 * (size_t)vtile * vgrid.x));
             V.wide_idx = b->wide_idx.as<uint32_t>(); V.wide_cnt = c_wide;
          }
 #define GM_VERIFY(N) do { if (pairs) hipLaunchKernelGGL((k_verify<N, true>), vgrid, dim3(vbd), 0, st, V); \
@@ -1061,8 +1066,8 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
          const int64_t n_class[2] = {(int64_t)h_tot[2] - (int64_t)h_tot[1], (int64_t)h_tot[3] - (int64_t)h_tot[2]};
          if (n_iv > 0) {
             HIP_TRY(b->iv_dense.ensure(4 * (size_t)n_iv));
-            hipLaunchKernelGGL(k_list_compact, vgrid, dim3(STAGE_PER_BLOCK), 0, st, b->iv_idx.as<const uint32_t>(), (const uint32_t *)c_iv,
-                               (const uint32_t *)o_iv, STAGE_PER_BLOCK, b->iv_dense.as<uint32_t>() - h_tot[0]);
+            hipLaunchKernelGGL(k_list_compact, vgrid, dim3(64), 0, st, b->iv_idx.as<const uint32_t>(), (const uint32_t *)c_iv,
+                               (const uint32_t *)o_iv, vtile, b->iv_dense.as<uint32_t>() - h_tot[0]);
          }
          // the two classes of big candidates: a dense list each, then k_verify_group with 4 / 16 lanes per entry
          bool any_group = false;
@@ -1074,8 +1079,8 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
             const int G = c == 0 ? 4 : use_verify;
             DevBuf &dense_buf = c == 0 ? b->big_dense : b->wide_dense;
             HIP_TRY(dense_buf.ensure(4 * (size_t)n_big));
-            hipLaunchKernelGGL(k_list_compact, vgrid, dim3(BIG_PER_BLOCK), 0, st, (c == 0 ? b->big_idx : b->wide_idx).as<const uint32_t>(),
-                               (const uint32_t *)(c == 0 ? c_big : c_wide), (const uint32_t *)(c == 0 ? o_big : o_wide), BIG_PER_BLOCK,
+            hipLaunchKernelGGL(k_list_compact, vgrid, dim3(64), 0, st, (c == 0 ? b->big_idx : b->wide_idx).as<const uint32_t>(),
+                               (const uint32_t *)(c == 0 ? c_big : c_wide), (const uint32_t *)(c == 0 ? o_big : o_wide), vtile,
                                dense_buf.as<uint32_t>() - h_tot[1 + c]);
             const dim3 ggrid((unsigned)cdiv((int64_t)G * n_big, vbd));
             gblocks[c] = ggrid.x;
@@ -1164,12 +1169,12 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
          HIP_TRY(b->keys.ensure(8 * (size_t)L));
          HIP_TRY(b->keys_alt.ensure(8 * (size_t)L));
          if (n_stage1 > 0)
-            hipLaunchKernelGGL(k_stage_compact, dim3(vblocks), dim3(STAGE_PER_BLOCK), 0, st, b->stage.as<const unsigned long long>(),
-                               b->blk_cnt.as<const uint32_t>(), b->blk_off.as<const uint32_t>(), b->keys.as<unsigned long long>());
+            hipLaunchKernelGGL(k_stage_compact, dim3(vblocks), dim3(256), 0, st, b->stage.as<const unsigned long long>(),
+                               b->blk_cnt.as<const uint32_t>(), b->blk_off.as<const uint32_t>(), vstage_per, b->keys.as<unsigned long long>());
          for (int c = 0; c < 2; c++)
             if (n_stage2[c] > 0)
-               hipLaunchKernelGGL(k_stage_compact, dim3(gblocks[c]), dim3(STAGE_PER_BLOCK), 0, st, b->stage2[c].as<const unsigned long long>(),
-                                  b->blk_cnt2[c].as<const uint32_t>(), b->blk_off2[c].as<const uint32_t>(),
+               hipLaunchKernelGGL(k_stage_compact, dim3(gblocks[c]), dim3(256), 0, st, b->stage2[c].as<const unsigned long long>(),
+                                  b->blk_cnt2[c].as<const uint32_t>(), b->blk_off2[c].as<const uint32_t>(), STAGE_PER_BLOCK,
                                   b->keys.as<unsigned long long>() + n_stage1 + (c == 1 ? n_stage2[0] : 0));
          if (L_iv > 0) {
             unsigned long long *keys_iv = b->keys.as<unsigned long long>() + n_stage1 + n_stage2[0] + n_stage2[1];

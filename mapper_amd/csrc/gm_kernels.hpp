@@ -432,17 +432,20 @@ struct VerifyArgs {
    int stride;
    unsigned long long *n_ext;      // [blocks of the launch] steps per block (atomics on a few hot words cost a fifth of the kernel)
    int key_shift;                  // key = read << key_shift | text position << 4 | score (as k_place)
-   // Per block of the launch, no atomics: the sort keys of the hits its candidates became (a slot of STAGE_PER_BLOCK
-   // keys per block, filled from its start: k_stage_compact makes them dense), the entries that are hits of k_search
-   // itself (intervals: the locate stage reads their suffix-array entries) and the entries that hold more than two
-   // suffixes (k_verify_group), as lists of entry numbers.
+   int tile;                       // k_verify: entries of the list a block takes (<= VERIFY_TILE_MAX)
+   int stage_per;                  // k_verify: keys of a block's slot of the staging area (2 * tile with pairs, else tile)
+   // Per block of the launch, no global atomics: the sort keys of the hits its candidates became (a slot of stage_per
+   // keys per block (k_verify_group: STAGE_PER_BLOCK), filled from its start: k_stage_compact makes them dense), the
+   // entries that are hits of k_search itself (intervals: the locate stage reads their suffix-array entries) and the
+   // entries that hold more than two suffixes (k_verify_group), as lists of entry numbers in slots of `tile`.
    unsigned long long *stage;
    uint32_t *stage_cnt;
    uint32_t *iv_idx, *iv_cnt;
    uint32_t *big_idx, *big_cnt;    // candidates of 3 .. 4 suffixes (nullptr: there are none)
    uint32_t *wide_idx, *wide_cnt;  // candidates of 5 .. 16 suffixes (nullptr: there are none)
 };
-constexpr int STAGE_PER_BLOCK = 256;     // keys a block of 256 lanes can produce (one per lane)
+constexpr int STAGE_PER_BLOCK = 256;     // keys a block of k_verify_group can produce (one per lane)
+constexpr int VERIFY_TILE_MAX = 1024;    // entries a block of k_verify takes at most
 
 // The query row and the text window of a candidate are read as bit planes (k_pack_planes: 16 bytes per
 // plane and 128 symbols; every lane of a load touches a line of its own, so the number of load
@@ -697,10 +700,9 @@ __device__ __forceinline__ uint32_t verify_walked_td(const VerifyArgs &A, const 
 
 // Per block: steps in the low half, windows in the high half (k_sum_steps adds the words up: the halves of its 64
 // sums stay below 2^32 for launches of up to 2^38 steps).  Ends with a workgroup barrier.
-__device__ __forceinline__ void verify_block_sums(uint32_t steps, bool mine, unsigned long long *out)
+__device__ __forceinline__ void verify_block_sums(uint32_t steps, uint32_t windows /* suffixes this lane replayed */, unsigned long long *out)
 {
-   for (int o = 32; o > 0; o >>= 1) steps += (uint32_t)__shfl_xor((int)steps, o);
-   const uint32_t windows = (uint32_t)__popcll(__ballot(mine));          // suffixes this wave replayed
+   for (int o = 32; o > 0; o >>= 1) { steps += (uint32_t)__shfl_xor((int)steps, o); windows += (uint32_t)__shfl_xor((int)windows, o); }
    __shared__ uint32_t s_steps[4], s_windows[4];
    if ((threadIdx.x & 63) == 0) { s_steps[threadIdx.x >> 6] = steps; s_windows[threadIdx.x >> 6] = windows; }
    __syncthreads();
@@ -708,139 +710,141 @@ __device__ __forceinline__ void verify_block_sums(uint32_t steps, bool mine, uns
                                            (((unsigned long long)s_windows[0] + s_windows[1] + s_windows[2] + s_windows[3]) << 32);
 }
 
-constexpr int BIG_PER_BLOCK = 128;                         // entries of a k_verify<*, true> block (two lanes each)
+// A slot of a list the lanes of a block fill together: the lanes of the wave that hold `flag` get consecutive slots from
+// `counter` (in LDS; one atomic per wave).  Converged call: every lane of the wave executes it.
+__device__ __forceinline__ uint32_t wave_slot(bool flag, uint32_t *counter, int lane)
+{
+   const unsigned long long m = __ballot(flag);
+   uint32_t base = 0;
+   if (lane == 0 && m != 0) base = atomicAdd(counter, (uint32_t)__popcll(m));
+   base = (uint32_t)__shfl((int)base, 0);
+   return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+}
 
-// PAIRS: two lanes per entry of the list.  An entry that is a candidate then holds one or two suffixes;
-// lane q of the pair replays suffix q.  The two walks of a pair share the nodes of the reference's search
-// tree as long as the two places of the text spell the same letters along the walk: those steps are
-// counted once.  Without PAIRS every candidate holds one suffix and an entry has one lane.
-// Candidates of more than two suffixes (option verify = 4: up to four) are left to k_verify_group: this kernel
-// only lists them, per block (A.big_idx, A.big_cnt; no atomics).
+// A block takes a tile of A.tile entries of the list.  It first sorts them by what they are: candidates of two
+// suffixes (PAIRS only), candidates of one suffix, hits of k_search itself (intervals: listed for the locate stage),
+// candidates of more suffixes (option verify >= 4: listed for k_verify_group).  The suffixes to replay then fill the
+// lanes densely, 256 per round: two adjacent lanes per pair (lane q replays suffix q), one lane per single; with
+// one lane (or two) per ENTRY a third of the lanes had nothing to replay.  The two walks of a pair share the nodes of
+// the reference's search tree as long as the two places of the text spell the same letters along the walk: those
+// steps are counted once.  Without PAIRS every candidate holds one suffix.
+// The order of the keys and of the lists inside a block's slots depends on the order the waves arrive in: the sort
+// that follows makes the result the same.
 template <int NCH, bool PAIRS>
 __global__ void __launch_bounds__(256) k_verify(VerifyArgs A)
 {
-   constexpr bool pairs = PAIRS;
-   const int64_t th = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-   const int64_t i = PAIRS ? th >> 1 : th;
-   const int q = PAIRS ? (int)(th & 1) : 0;
-   uint32_t steps = 0;                 // this walk's steps (0 for a lane without a suffix)
-   unsigned long long key = ~0ull;
-   bool cand = false, pair = false, big = false, wide = false;
-   int64_t p0 = 0;
-   uint32_t read = 0;
-   int row = 0;
-   int phase0 = 0, pos0 = 0, end0 = 0;
-   bool fw0 = false;
-   uint64_t E[NCH], S[NCH], QN[NCH];
-#pragma unroll
-   for (int c = 0; c < NCH; c++) { E[c] = 0; S[c] = 0; QN[c] = 0; }
-   uint32_t tw[3][2 * NCH];            // the window's planes, kept for the pair (where the two places of the text differ)
-#pragma unroll
-   for (int p = 0; p < 3; p++)
-#pragma unroll
-      for (int w = 0; w < 2 * NCH; w++) tw[p][w] = 0;
-   bool planes = false;                // tw holds this lane's window
+   const int lane = threadIdx.x & 63;
+   __shared__ uint16_t s_pairs[VERIFY_TILE_MAX], s_singles[VERIFY_TILE_MAX];
+   __shared__ uint32_t s_n[6];         // pairs, singles, intervals, big, wide, keys
+   if (threadIdx.x < 6) s_n[threadIdx.x] = 0;
+   __syncthreads();
+   const int64_t tile0 = blockIdx.x * (int64_t)A.tile;
+   for (int e0 = 0; e0 < A.tile; e0 += 256) {
+      const int e = e0 + (int)threadIdx.x;
+      const int64_t i = tile0 + e;
+      int kind = 0;                    // 1: pair, 2: single, 3: interval, 4: three or four suffixes, 5: more
+      if (e < A.tile && i < A.n_list) {
+         const Node &nd = A.list[i];
+         const uint32_t w2 = nd.w[2], w3 = nd.w[3], w5 = nd.w[5];
+         if (w5 >> META_CAND) kind = !PAIRS ? 2 : w2 == 2 ? 1 : w2 > 4 ? 5 : w2 > 2 ? 4 : 2;
+         else if ((w2 | ((w3 >> 16) & 0xff)) != 0) kind = 3;      // (else a hole of the list)
+      }
+      uint32_t s;
+      if (PAIRS) { s = wave_slot(kind == 1, &s_n[0], lane); if (kind == 1) s_pairs[s] = (uint16_t)e; }
+      s = wave_slot(kind == 2, &s_n[1], lane); if (kind == 2) s_singles[s] = (uint16_t)e;
+      s = wave_slot(kind == 3, &s_n[2], lane); if (kind == 3) A.iv_idx[(size_t)blockIdx.x * A.tile + s] = (uint32_t)i;
+      if (PAIRS && A.big_idx != nullptr) { s = wave_slot(kind == 4, &s_n[3], lane); if (kind == 4) A.big_idx[(size_t)blockIdx.x * A.tile + s] = (uint32_t)i; }
+      if (PAIRS && A.wide_idx != nullptr) { s = wave_slot(kind == 5, &s_n[4], lane); if (kind == 5) A.wide_idx[(size_t)blockIdx.x * A.tile + s] = (uint32_t)i; }
+   }
+   __syncthreads();
+   const int n_pair_lanes = PAIRS ? 2 * (int)s_n[0] : 0, total = n_pair_lanes + (int)s_n[1];
    constexpr bool KEEP_PLANES = PAIRS && NCH <= 2;      // (longer reads: the registers cost more than the loads, 4.6 -> 4.9 ms at 150 nt)
-   bool interval = false;              // a hit of k_search itself (not a hole of the list)
-   if (i < A.n_list) {
-      const uint32_t w5 = A.list[i].w[5];
-      cand = w5 >> META_CAND;
-      if (!cand && q == 0) {
-         const Node &e = A.list[i];
-         interval = (e.w[2] | ((e.w[3] >> 16) & 0xff)) != 0;
+   uint32_t steps_sum = 0, windows = 0;
+   for (int base = (int)(threadIdx.x & ~63u); base < total; base += 256) {      // (per wave: a wave with nothing left to do leaves)
+      const int idx = base + lane;
+      const bool mine = idx < total;                    // this lane replays a suffix
+      const bool pair = idx < n_pair_lanes;
+      const int q = pair ? (idx & 1) : 0;
+      uint32_t steps = 0;                 // this walk's steps (0 for a lane without a suffix)
+      unsigned long long key = ~0ull;
+      int64_t p0 = 0;
+      uint32_t read = 0;
+      int row = 0;
+      int phase0 = 0, pos0 = 0, end0 = 0;
+      bool fw0 = false;
+      uint64_t E[NCH], S[NCH], QN[NCH];
+#pragma unroll
+      for (int c = 0; c < NCH; c++) { E[c] = 0; S[c] = 0; QN[c] = 0; }
+      uint32_t tw[3][2 * NCH];            // the window's planes, kept for the pair (where the two places of the text differ)
+#pragma unroll
+      for (int p = 0; p < 3; p++)
+#pragma unroll
+         for (int w = 0; w < 2 * NCH; w++) tw[p][w] = 0;
+      bool planes = false;                // tw holds this lane's window
+      if (mine) {
+         const int e = pair ? s_pairs[idx >> 1] : s_singles[idx - n_pair_lanes];
+         Node nd = A.list[tile0 + e];
+         verify_replay<NCH, KEEP_PLANES>(A, nd, q, E, S, QN, tw, planes, steps, key, p0, read, row, phase0, pos0, end0, fw0);
       }
-   }
-   bool mine = false;                  // this lane replays a suffix
-   if (cand) {
-      Node nd = A.list[i];
-      pair = PAIRS && nd.w[2] == 2;
-      wide = PAIRS && nd.w[2] > 4;
-      big = PAIRS && nd.w[2] > 2;                 // (the wide ones included: neither is replayed here)
-      mine = !big && (q == 0 || pair);
-   }
-   if (mine) {
-      Node nd = A.list[i];
-      verify_replay<NCH, KEEP_PLANES>(A, nd, q, E, S, QN, tw, planes, steps, key, p0, read, row, phase0, pos0, end0, fw0);
-   }
-   // ---- the pair: what the partner found (lanes 2k and 2k+1 of a wave; every lane takes part in the exchange)
-   uint32_t steps_o = 0, shared = 0;
-   int64_t p0_o = 0;
-   uint64_t Eo[NCH];
+      if (PAIRS) {
+         // ---- the pair: what the partner found (lanes 2k and 2k+1 of a wave; every lane takes part in the exchange)
+         const uint32_t steps_o = (uint32_t)__shfl_xor((int)steps, 1);
+         const int64_t p0_o = __shfl_xor(p0, 1);
+         uint64_t Eo[NCH];
 #pragma unroll
-   for (int c = 0; c < NCH; c++) Eo[c] = 0;
-   if (pairs) {
-      steps_o = (uint32_t)__shfl_xor((int)steps, 1);
-      p0_o = __shfl_xor(p0, 1);
+         for (int c = 0; c < NCH; c++) Eo[c] = __shfl_xor(E[c], 1);
+         // where the two windows differ, letter by letter, from the planes in registers (both lanes on the fast path)
+         uint64_t TD[NCH];
 #pragma unroll
-      for (int c = 0; c < NCH; c++) Eo[c] = __shfl_xor(E[c], 1);
-   }
-   // where the two windows differ, letter by letter, from the planes in registers (both lanes on the fast
-   // path; every lane takes part in the exchange)
-   uint64_t TD[NCH];
+         for (int c = 0; c < NCH; c++) TD[c] = 0;
+         bool planes_both = false;
+         if (KEEP_PLANES) {
+            const int planes_o = __shfl_xor((int)planes, 1);
+            planes_both = planes && planes_o != 0;
+            uint32_t dw[2 * NCH];
 #pragma unroll
-   for (int c = 0; c < NCH; c++) TD[c] = 0;
-   bool planes_both = false;
-   if (KEEP_PLANES) {
-      const int planes_o = __shfl_xor((int)planes, 1);
-      planes_both = planes && planes_o != 0;
-      uint32_t dw[2 * NCH];
+            for (int w = 0; w < 2 * NCH; w++) {
+               dw[w] = 0;
 #pragma unroll
-      for (int w = 0; w < 2 * NCH; w++) {
-         dw[w] = 0;
+               for (int p = 0; p < 3; p++) dw[w] |= tw[p][w] ^ (uint32_t)__shfl_xor((int)tw[p][w], 1);
+            }
 #pragma unroll
-         for (int p = 0; p < 3; p++) dw[w] |= tw[p][w] ^ (uint32_t)__shfl_xor((int)tw[p][w], 1);
+            for (int c = 0; c < NCH; c++) TD[c] = (uint64_t)dw[2 * c] | ((uint64_t)dw[2 * c + 1] << 32);
+         }
+         if (pair && q == 1) {
+            const uint32_t wk = planes_both ? verify_walked_td<NCH>(A, TD, row, phase0, pos0, end0, fw0)
+                                            : verify_walked<NCH>(A, E, Eo, QN, TD, false, p0, p0_o, row, phase0, pos0, end0, fw0);
+            steps -= min(wk, min(steps, steps_o));
+         }
       }
-#pragma unroll
-      for (int c = 0; c < NCH; c++) TD[c] = (uint64_t)dw[2 * c] | ((uint64_t)dw[2 * c + 1] << 32);
+      steps_sum += steps;
+      windows += mine ? 1u : 0u;
+      const bool found = mine && key != ~0ull;
+      const uint32_t s = wave_slot(found, &s_n[5], lane);
+      if (found) A.stage[(size_t)blockIdx.x * A.stage_per + s] = key;
    }
-   if (pair && q == 1) {
-      const uint32_t wk = planes_both ? verify_walked_td<NCH>(A, TD, row, phase0, pos0, end0, fw0)
-                                      : verify_walked<NCH>(A, E, Eo, QN, TD, false, p0, p0_o, row, phase0, pos0, end0, fw0);
-      shared = min(wk, min(steps, steps_o));
-   }
-   steps -= shared;
-   // what the block leaves behind: every lane's own hit key, the interval entries, the big candidates
-   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-   const unsigned long long lt = (1ull << lane) - 1ull;
-   const bool found = cand && !big && key != ~0ull;
-   const unsigned long long foundm = __ballot(found), ivm = __ballot(interval), bigm = __ballot(big && !wide && q == 0),
-                            widem = __ballot(wide && q == 0);
-   __shared__ uint32_t s_cnt[4][4];
-   if (lane == 0) {
-      s_cnt[0][w] = (uint32_t)__popcll(foundm); s_cnt[1][w] = (uint32_t)__popcll(ivm);
-      s_cnt[2][w] = (uint32_t)__popcll(bigm); s_cnt[3][w] = (uint32_t)__popcll(widem);
-   }
-   verify_block_sums(steps, mine, A.n_ext);         // (barrier inside)
-   uint32_t off[4] = {0, 0, 0, 0}, total[4] = {0, 0, 0, 0};
-#pragma unroll
-   for (int k = 0; k < 4; k++)
-#pragma unroll
-      for (int t = 0; t < 4; t++) { if (k < w) off[t] += s_cnt[t][k]; total[t] += s_cnt[t][k]; }
-   if (found) A.stage[(size_t)blockIdx.x * STAGE_PER_BLOCK + off[0] + (uint32_t)__popcll(foundm & lt)] = key;
-   if (interval) A.iv_idx[(size_t)blockIdx.x * STAGE_PER_BLOCK + off[1] + (uint32_t)__popcll(ivm & lt)] = (uint32_t)i;
-   if (PAIRS && A.big_idx != nullptr && big && !wide && q == 0)
-      A.big_idx[(size_t)blockIdx.x * BIG_PER_BLOCK + off[2] + (uint32_t)__popcll(bigm & lt)] = (uint32_t)i;
-   if (PAIRS && A.wide_idx != nullptr && wide && q == 0)
-      A.wide_idx[(size_t)blockIdx.x * BIG_PER_BLOCK + off[3] + (uint32_t)__popcll(widem & lt)] = (uint32_t)i;
+   verify_block_sums(steps_sum, windows, A.n_ext);         // (barrier inside)
    if (threadIdx.x == 0) {
-      A.stage_cnt[blockIdx.x] = total[0];
-      A.iv_cnt[blockIdx.x] = total[1];
-      if (PAIRS && A.big_idx != nullptr) A.big_cnt[blockIdx.x] = total[2];
-      if (PAIRS && A.wide_idx != nullptr) A.wide_cnt[blockIdx.x] = total[3];
+      A.stage_cnt[blockIdx.x] = s_n[5];
+      A.iv_cnt[blockIdx.x] = s_n[2];
+      if (PAIRS && A.big_idx != nullptr) A.big_cnt[blockIdx.x] = s_n[3];
+      if (PAIRS && A.wide_idx != nullptr) A.wide_cnt[blockIdx.x] = s_n[4];
    }
 }
 
 // The per-block slots of the staging area made dense: out[off[b] ..) = the first cnt[b] keys of slot b.
-__global__ void __launch_bounds__(STAGE_PER_BLOCK) k_stage_compact(const unsigned long long *stage, const uint32_t *cnt, const uint32_t *off,
-                                                                    unsigned long long *out)
+__global__ void __launch_bounds__(256) k_stage_compact(const unsigned long long *stage, const uint32_t *cnt, const uint32_t *off, int per,
+                                                       unsigned long long *out)
 {
-   if (threadIdx.x < cnt[blockIdx.x]) out[off[blockIdx.x] + threadIdx.x] = stage[(size_t)blockIdx.x * STAGE_PER_BLOCK + threadIdx.x];
+   const uint32_t n = cnt[blockIdx.x];
+   for (uint32_t t = threadIdx.x; t < n; t += blockDim.x) out[off[blockIdx.x] + t] = stage[(size_t)blockIdx.x * per + t];
 }
 
 // The same for the per-block lists of entry numbers (slots of `per` numbers).
 __global__ void k_list_compact(const uint32_t *idx, const uint32_t *cnt, const uint32_t *off, int per, uint32_t *dense)
 {
-   if (threadIdx.x < cnt[blockIdx.x]) dense[off[blockIdx.x] + threadIdx.x] = idx[(size_t)blockIdx.x * per + threadIdx.x];
+   const uint32_t n = cnt[blockIdx.x];
+   for (uint32_t t = threadIdx.x; t < n; t += blockDim.x) dense[off[blockIdx.x] + t] = idx[(size_t)blockIdx.x * per + t];
 }
 
 // Candidates of three to G suffixes: G lanes per entry, lane q replays suffix q.  The walks of one entry are paths
@@ -948,7 +952,7 @@ __global__ void __launch_bounds__(256) k_verify_group(VerifyArgs A, const uint32
    const unsigned long long foundm = __ballot(found);
    __shared__ uint32_t s_found[4];
    if (lane == 0) s_found[threadIdx.x >> 6] = (uint32_t)__popcll(foundm);
-   verify_block_sums(steps, mine, n_ext_out);       // (barrier inside)
+   verify_block_sums(steps, mine ? 1u : 0u, n_ext_out);       // (barrier inside)
    uint32_t off = 0, total = 0;
 #pragma unroll
    for (int k = 0; k < 4; k++) { if (k < (int)(threadIdx.x >> 6)) off += s_found[k]; total += s_found[k]; }
