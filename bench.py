@@ -66,8 +66,8 @@ class _DevPtr:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default=os.environ.get("GPUMAP_WORKLOAD", "grch38"))
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU (0 = the workload's)")
     ap.add_argument("--chunks", type=int, default=8, help="distinct chunks of reads per GPU resident in HBM")
@@ -367,7 +367,7 @@ def main():
             "stages_ms": {"encode": mean["encode"], "search": mean["k_search"] + mean["k_verify"], "locate": mean["locate"],
                           "order": mean["order"], "chunk_on_device": mean["device_total"]},
             "hits_per_batch": {"list_entries": c["n_hits"], "list_length": c["list_length"], "located": c["n_locs"],
-                               "verify_windows": W},
+                               "verify_windows": W, "big_candidates": e["big_candidates"]},
             "occupancy": {"loop_passes": c["loop_passes"], "continuations": c["continuations"],
                           "steps_from_jump_table": c["jumped_steps"], "steps_replayed_on_text": c["verify_steps"],
                           "steps_on_occ_table": occ_steps,

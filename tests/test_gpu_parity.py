@@ -399,3 +399,36 @@ def test_sharded_batches_concatenate_in_input_order(workdir):
             parts.append(loc)
         assert np.array_equal(np.concatenate(parts), whole)
     ctx.close()
+
+
+def test_verify_tile_changes_nothing(workdir):
+    """Option verify_tile (entries of the list a workgroup of k_verify takes and hands out to its lanes suffix by
+    suffix) changes where the work is done, not the result: the oracle's located hits and its count of extension
+    steps for tiles of 1, 64, 257 and 1024 entries (1: a round per entry; 257: a second pass of the tile's first look
+    with one entry), with one lane per candidate (verify 1), pairs (2) and groups (4); values out of range are refused."""
+    rng = np.random.default_rng(77)
+    a = rng.integers(0, 4, 30_000).astype(np.uint8)
+    seqs = []
+    for c in range(4):
+        b = a.copy()
+        hit = rng.random(len(b)) < 0.02
+        b[hit] = (b[hit] + rng.integers(1, 4, int(hit.sum()))) % 4
+        seqs.append(b)
+    seqs[2][500:520] = 4
+    base = os.path.join(workdir, "tiles")
+    ma.HostIndex.build_codes(seqs, ["c%d" % c for c in range(4)], base).close()
+    ctx = ma.Context.from_files(base, 0)
+    orc = po.Index(base)
+    codes, offs = synth.make_reads(seqs, 3000, 80, 2, seed=78, n_frac=0.02)
+    d = orc.map_batch(codes.reshape(-1), offs, 2, threads=8)
+    for verify in (1, 2, 4):
+        ctx.set_option("verify", verify)
+        for tile in (1, 64, 257, 1024, 0):
+            ctx.set_option("verify_tile", tile)
+            h = ctx.map_batch(codes.reshape(-1), offs, 2)
+            assert np.array_equal(h.located(), d.located()), (verify, tile)
+            assert h.n_ext == d.n_ext, (verify, tile)
+    for bad in (-1, 1025):
+        with pytest.raises(ma.GpumapError):
+            ctx.set_option("verify_tile", bad)
+    ctx.close()

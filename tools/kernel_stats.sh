@@ -5,8 +5,8 @@ R=$GRAFT_REPO_ROOT
 raw=/tmp/gpumap_ks_$$
 mkdir -p $R/$out $raw
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $raw -- python3 $R/bench.py --workload $w --steps 2 --warmup 1 --no-cpu-baseline > $raw/line.json 2> $raw/err.txt || { tail -5 $raw/err.txt; exit 1; }
-cp $raw/*/*kernel_stats.csv $R/$out/kernel_stats_$w.csv
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $raw -- python3 $R/bench.py --workload $w --steps 2 --warmup 1 --no-cpu-baseline --no-pcie > $raw/line.json 2> $raw/err.txt || { tail -5 $raw/err.txt; exit 1; }
+cp "$(ls -S $(find $raw -name "*kernel_stats.csv") | head -1)" $R/$out/kernel_stats_$w.csv; cp $raw/line.json $R/$out/line_$w.json
 python3 - $R/$out/kernel_stats_$w.csv <<'PY'
 import csv,sys
 rows=list(csv.DictReader(open(sys.argv[1])))
