@@ -73,6 +73,7 @@ struct gpumap_ctx {
    int64_t wil_cnt = 0;
    // nodes whose interval holds one suffix are finished against the text (k_verify) when the text is in
    // HBM (d_text) and the caller wants located hits only
+   bool sort_all_bits = false;    // option "sort_all_bits": 1 = the radix sort of the located hits runs over every bit of the keys (no k_order_runs)
    int verify_tile = 0;           // option "verify_tile": entries of the hit list a block of k_verify takes (0: 512)
    int verify = -1;               // option "verify": 0 off, 1 nodes of one suffix, 2 also of two, -1 by the size of the text
    bool owns_text = true;

@@ -1175,6 +1175,27 @@ __global__ void k_status(const uint16_t *read_len, const uint16_t *len_row, int6
    status[r] = (m <= MAX_READ && len_row[m] != NO_ROW) ? 0 : -1;
 }
 
+// The radix sort may leave out the lowest bits of the key when that saves it a pass over the keys (the score, which
+// the text position determines, and up to three bits of the position): keys that agree in all bits from `shift` on are
+// neighbours then, in any order.  The thread of the first key of such a run puts the run in order; runs are short (at
+// most 2^(shift - 4) places of the text, each found from a few seeds).  The other threads only look at bits that no
+// reordering inside a run changes.
+__global__ void k_order_runs(unsigned long long *keys, int64_t n, int shift)
+{
+   const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+   if (t >= n) return;
+   const unsigned long long g = keys[t] >> shift;
+   if (t > 0 && (keys[t - 1] >> shift) == g) return;
+   int64_t e = t + 1;
+   while (e < n && (keys[e] >> shift) == g) e++;
+   for (int64_t i = t + 1; i < e; i++) {
+      const unsigned long long k = keys[i];
+      int64_t j = i;
+      while (j > t && keys[j - 1] > k) { keys[j] = keys[j - 1]; j--; }
+      if (j != i) keys[j] = k;
+   }
+}
+
 // Compact results: the sorted keys are the output; only the CSR offsets of the reads are derived from them
 // (as k_unpack_locs does: the thread of the first key of a read writes that read's offset and those of the
 // reads without hits before it).

@@ -432,3 +432,46 @@ def test_verify_tile_changes_nothing(workdir):
         with pytest.raises(ma.GpumapError):
             ctx.set_option("verify_tile", bad)
     ctx.close()
+
+
+@pytest.mark.parametrize("n_reads", [1, 5, 40, 300, 2100])
+def test_sort_that_skips_low_bits_gives_the_same_order(workdir, n_reads):
+    """The radix sort of the located hits leaves out the score and up to three low bits of the text position where that
+    saves a pass, and k_order_runs orders the runs of keys that agree above (gm_device.hip, "order").  On a text with
+    homopolymer and dinucleotide runs a read hits many adjacent positions, each from several seeds: the located hits
+    must come in the oracle's order (read, text position) with either sort, for batch sizes that move the key's
+    width across the pass boundaries."""
+    rng = np.random.default_rng(5)
+    parts = [rng.integers(0, 4, 3000).astype(np.uint8), np.zeros(300, np.uint8), rng.integers(0, 4, 2000).astype(np.uint8),
+             np.tile(np.array([1, 2], np.uint8), 200), rng.integers(0, 4, 1500).astype(np.uint8)]
+    seq = np.concatenate(parts)
+    base = os.path.join(workdir, "runs")
+    if not os.path.exists(base + ".sar"):
+        ma.HostIndex.build_codes([seq], ["r"], base).close()
+    ctx = ma.Context.from_files(base, 0)
+    orc = po.Index(base)
+    reads = []
+    for i in range(n_reads):
+        kind = i % 4
+        if kind == 0:
+            w = np.zeros(40, np.uint8)                                   # poly-A: every shift inside the run
+        elif kind == 1:
+            w = np.tile(np.array([1, 2], np.uint8), 20)                  # CG repeat: every second shift
+        elif kind == 2:
+            w = np.zeros(40, np.uint8); w[rng.integers(0, 40)] = 3       # poly-A with a substitution
+        else:
+            s0 = int(rng.integers(0, len(seq) - 40)); w = seq[s0:s0 + 40].copy()
+        reads.append(w)
+    codes = np.concatenate(reads)
+    offs = np.arange(0, 40 * (n_reads + 1), 40, dtype=np.int64)
+    d = orc.map_batch(codes, offs, 2, threads=8)
+    got = {}
+    for all_bits in (1, 0):
+        ctx.set_option("sort_all_bits", all_bits)
+        for verify in (4, 1, 0):
+            ctx.set_option("verify", verify)
+            h = ctx.map_batch(codes, offs, 2)
+            assert np.array_equal(h.located(), d.located()), (all_bits, verify)
+            assert h.n_ext == d.n_ext
+    assert len(d.located()) > 100 * min(n_reads, 3)
+    ctx.close()
