@@ -698,6 +698,12 @@ __device__ __forceinline__ uint32_t verify_walked_td(const VerifyArgs &A, const 
    }
 }
 
+// The value of the other lane of a pair (lanes 2k and 2k + 1): a DPP move inside the quad, no trip through the LDS
+// crossbar (`__shfl_xor(v, 1)` becomes ds_bpermute_b32).
+__device__ __forceinline__ uint32_t pair_swap(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true); }
+__device__ __forceinline__ uint64_t pair_swap(uint64_t v) { return (uint64_t)pair_swap((uint32_t)v) | ((uint64_t)pair_swap((uint32_t)(v >> 32)) << 32); }
+__device__ __forceinline__ int64_t pair_swap(int64_t v) { return (int64_t)pair_swap((uint64_t)v); }
+
 // Per block: steps in the low half, windows in the high half (k_sum_steps adds the words up: the halves of its 64
 // sums stay below 2^32 for launches of up to 2^38 steps).  Ends with a workgroup barrier.
 __device__ __forceinline__ void verify_block_sums(uint32_t steps, uint32_t windows /* suffixes this lane replayed */, unsigned long long *out)
@@ -788,25 +794,25 @@ __global__ void __launch_bounds__(256) k_verify(VerifyArgs A)
       }
       if (PAIRS) {
          // ---- the pair: what the partner found (lanes 2k and 2k+1 of a wave; every lane takes part in the exchange)
-         const uint32_t steps_o = (uint32_t)__shfl_xor((int)steps, 1);
-         const int64_t p0_o = __shfl_xor(p0, 1);
+         const uint32_t steps_o = pair_swap(steps);
+         const int64_t p0_o = pair_swap(p0);
          uint64_t Eo[NCH];
 #pragma unroll
-         for (int c = 0; c < NCH; c++) Eo[c] = __shfl_xor(E[c], 1);
+         for (int c = 0; c < NCH; c++) Eo[c] = pair_swap(E[c]);
          // where the two windows differ, letter by letter, from the planes in registers (both lanes on the fast path)
          uint64_t TD[NCH];
 #pragma unroll
          for (int c = 0; c < NCH; c++) TD[c] = 0;
          bool planes_both = false;
          if (KEEP_PLANES) {
-            const int planes_o = __shfl_xor((int)planes, 1);
+            const uint32_t planes_o = pair_swap((uint32_t)planes);
             planes_both = planes && planes_o != 0;
             uint32_t dw[2 * NCH];
 #pragma unroll
             for (int w = 0; w < 2 * NCH; w++) {
                dw[w] = 0;
 #pragma unroll
-               for (int p = 0; p < 3; p++) dw[w] |= tw[p][w] ^ (uint32_t)__shfl_xor((int)tw[p][w], 1);
+               for (int p = 0; p < 3; p++) dw[w] |= tw[p][w] ^ pair_swap(tw[p][w]);
             }
 #pragma unroll
             for (int c = 0; c < NCH; c++) TD[c] = (uint64_t)dw[2 * c] | ((uint64_t)dw[2 * c + 1] << 32);
