@@ -1209,12 +1209,12 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
          HIP_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp, db, (int)L, begin_bit, end_bit, st));
          HIP_TRY(b->cub_tmp.ensure(tmp));
          HIP_TRY(hipcub::DeviceRadixSort::SortKeys(b->cub_tmp.p, tmp, db, (int)L, begin_bit, end_bit, st));
-         if (begin_bit > 0) hipLaunchKernelGGL(k_order_runs, dim3((unsigned)cdiv(L, 256)), dim3(256), 0, st, db.Current(), L, begin_bit);
          b->sorted_keys = db.Current();
          if (compact) {
-            hipLaunchKernelGGL(k_read_first, dim3((unsigned)cdiv(L, 256)), dim3(256), 0, st, b->sorted_keys, L, pos_bits, R,
-                               b->read_first.as<int64_t>());
+            hipLaunchKernelGGL(k_read_first, dim3((unsigned)cdiv(L, 256)), dim3(256), 0, st, db.Current(), L, pos_bits, R,
+                               b->read_first.as<int64_t>(), begin_bit);
          } else {
+            if (begin_bit > 0) hipLaunchKernelGGL(k_order_runs, dim3((unsigned)cdiv(L, 256)), dim3(256), 0, st, db.Current(), L, begin_bit);
             for (DevBuf *x : {&b->loc_read, &b->loc_pos, &b->loc_fwd, &b->loc_seq, &b->loc_seqpos}) HIP_TRY(x->ensure(8 * (size_t)L));
             HIP_TRY(b->loc_strand.ensure((size_t)L));
             HIP_TRY(b->loc_score.ensure((size_t)L));

@@ -1186,10 +1186,8 @@ __global__ void k_status(const uint16_t *read_len, const uint16_t *len_row, int6
 // neighbours then, in any order.  The thread of the first key of such a run puts the run in order; runs are short (at
 // most 2^(shift - 4) places of the text, each found from a few seeds).  The other threads only look at bits that no
 // reordering inside a run changes.
-__global__ void k_order_runs(unsigned long long *keys, int64_t n, int shift)
+__device__ __forceinline__ void order_run_from(unsigned long long *keys, int64_t n, int shift, int64_t t)
 {
-   const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-   if (t >= n) return;
    const unsigned long long g = keys[t] >> shift;
    if (t > 0 && (keys[t - 1] >> shift) == g) return;
    int64_t e = t + 1;
@@ -1202,13 +1200,22 @@ __global__ void k_order_runs(unsigned long long *keys, int64_t n, int shift)
    }
 }
 
+__global__ void k_order_runs(unsigned long long *keys, int64_t n, int shift)
+{
+   const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+   if (t < n) order_run_from(keys, n, shift, t);
+}
+
 // Compact results: the sorted keys are the output; only the CSR offsets of the reads are derived from them
 // (as k_unpack_locs does: the thread of the first key of a read writes that read's offset and those of the
 // reads without hits before it).
-__global__ void k_read_first(const unsigned long long *keys, int64_t n_locs, int pos_bits, int64_t n_reads, int64_t *read_first)
+// run_shift > 0: the sort left out the bits below it, and this kernel orders the runs as k_order_runs does (the read's
+// bits, which the offsets are made of, lie above and stay where they are).
+__global__ void k_read_first(unsigned long long *keys, int64_t n_locs, int pos_bits, int64_t n_reads, int64_t *read_first, int run_shift)
 {
    int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
    if (t >= n_locs) return;
+   if (run_shift > 0) order_run_from(keys, n_locs, run_shift, t);
    const int64_t read = (int64_t)(keys[t] >> (pos_bits + 4));
    const int64_t before = t == 0 ? -1 : (int64_t)(keys[t - 1] >> (pos_bits + 4));
    for (int64_t r = before + 1; r <= read; r++) read_first[r] = t;

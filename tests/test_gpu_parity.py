@@ -465,13 +465,14 @@ def test_sort_that_skips_low_bits_gives_the_same_order(workdir, n_reads):
     codes = np.concatenate(reads)
     offs = np.arange(0, 40 * (n_reads + 1), 40, dtype=np.int64)
     d = orc.map_batch(codes, offs, 2, threads=8)
-    got = {}
     for all_bits in (1, 0):
         ctx.set_option("sort_all_bits", all_bits)
-        for verify in (4, 1, 0):
-            ctx.set_option("verify", verify)
-            h = ctx.map_batch(codes, offs, 2)
-            assert np.array_equal(h.located(), d.located()), (all_bits, verify)
-            assert h.n_ext == d.n_ext
+        for compact in (0, 1):                       # (compact results: the runs are ordered inside k_read_first)
+            ctx.set_option("compact_results", compact)
+            for verify in (4, 1, 0):
+                ctx.set_option("verify", verify)
+                h = ctx.map_batch(codes, offs, 2)
+                assert np.array_equal(h.located(), d.located()), (all_bits, compact, verify)
+                assert h.n_ext == d.n_ext
     assert len(d.located()) > 100 * min(n_reads, 3)
     ctx.close()
