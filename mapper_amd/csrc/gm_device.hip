@@ -1008,7 +1008,9 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
          const int vbd = 256;
          const bool pairs = use_verify >= 2;                             // two lanes per entry
          const bool groups = use_verify >= 4;                            // entries of three and four suffixes go to k_verify_group<4>
-         const bool wides = use_verify >= 8;                             // those of five to eight (sixteen) to k_verify_group<8> (<16>)
+         const bool wides = use_verify >= 4;                             // those of five to eight (sixteen) to k_verify_group<8> (<16>); verify = 4: those of
+                                                                         // three to k_verify_group<3> (21 entries per wave instead of 16 with a lane idle each)
+         V.split3 = use_verify == 4;
          // entries a block takes: with pairs about 1.4 suffixes to replay per entry: rounds of 256 lanes, only the last one of a block partly filled
          const int vtile = ctx->verify_tile > 0 ? ctx->verify_tile : 512;
          V.tile = vtile; V.stage_per = pairs ? 2 * vtile : vtile;
@@ -1077,13 +1079,13 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
             n_stage2[c] = 0; gblocks[c] = 0;
             if (n_big <= 0) continue;
             any_group = true;
-            const int G = c == 0 ? 4 : use_verify;
+            const int G = c == 0 ? 4 : (use_verify == 4 ? 3 : use_verify);
             DevBuf &dense_buf = c == 0 ? b->big_dense : b->wide_dense;
             HIP_TRY(dense_buf.ensure(4 * (size_t)n_big));
             hipLaunchKernelGGL(k_list_compact, vgrid, dim3(64), 0, st, (c == 0 ? b->big_idx : b->wide_idx).as<const uint32_t>(),
                                (const uint32_t *)(c == 0 ? c_big : c_wide), (const uint32_t *)(c == 0 ? o_big : o_wide), vtile,
                                dense_buf.as<uint32_t>() - h_tot[1 + c]);
-            const dim3 ggrid((unsigned)cdiv((int64_t)G * n_big, vbd));
+            const dim3 ggrid((unsigned)cdiv(n_big, (int64_t)(vbd / 64) * (64 / G)));
             gblocks[c] = ggrid.x;
             HIP_TRY(b->vsteps2[c].ensure(8 * (size_t)ggrid.x));
             HIP_TRY(b->stage2[c].ensure(8 * (size_t)STAGE_PER_BLOCK * ggrid.x));
@@ -1094,6 +1096,8 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
             V2.stage = b->stage2[c].as<unsigned long long>(); V2.stage_cnt = b->blk_cnt2[c].as<uint32_t>();
 #define GM_GROUP(N) do { if (c == 0) hipLaunchKernelGGL((k_verify_group<N, 4>), ggrid, dim3(vbd), 0, st, V2, dense_buf.as<const uint32_t>(), n_big, \
                                                           b->vsteps2[c].as<unsigned long long>()); \
+                         else if (G == 3) hipLaunchKernelGGL((k_verify_group<N, 3>), ggrid, dim3(vbd), 0, st, V2, dense_buf.as<const uint32_t>(), n_big, \
+                                                 b->vsteps2[c].as<unsigned long long>()); \
                          else if (G == 8) hipLaunchKernelGGL((k_verify_group<N, 8>), ggrid, dim3(vbd), 0, st, V2, dense_buf.as<const uint32_t>(), n_big, \
                                                  b->vsteps2[c].as<unsigned long long>()); \
                          else hipLaunchKernelGGL((k_verify_group<N, 16>), ggrid, dim3(vbd), 0, st, V2, dense_buf.as<const uint32_t>(), n_big, \

@@ -442,7 +442,8 @@ struct VerifyArgs {
    uint32_t *stage_cnt;
    uint32_t *iv_idx, *iv_cnt;
    uint32_t *big_idx, *big_cnt;    // candidates of 3 .. 4 suffixes (nullptr: there are none)
-   uint32_t *wide_idx, *wide_cnt;  // candidates of 5 .. 16 suffixes (nullptr: there are none)
+   uint32_t *wide_idx, *wide_cnt;  // candidates of 5 .. 16 suffixes (nullptr: there are none); with split3 those of three
+   int split3;                     // 1 (option verify = 4): candidates of three suffixes go to the second list (three lanes each), those of four to the first
 };
 constexpr int STAGE_PER_BLOCK = 256;     // keys a block of k_verify_group can produce (one per lane)
 constexpr int VERIFY_TILE_MAX = 1024;    // entries a block of k_verify takes at most
@@ -752,7 +753,7 @@ __global__ void __launch_bounds__(256) k_verify(VerifyArgs A)
       if (e < A.tile && i < A.n_list) {
          const Node &nd = A.list[i];
          const uint32_t w2 = nd.w[2], w3 = nd.w[3], w5 = nd.w[5];
-         if (w5 >> META_CAND) kind = !PAIRS ? 2 : w2 == 2 ? 1 : w2 > 4 ? 5 : w2 > 2 ? 4 : 2;
+         if (w5 >> META_CAND) kind = !PAIRS ? 2 : w2 == 2 ? 1 : (w2 > 4 || (A.split3 && w2 == 3)) ? 5 : w2 > 2 ? 4 : 2;
          else if ((w2 | ((w3 >> 16) & 0xff)) != 0) kind = 3;      // (else a hole of the list)
       }
       uint32_t s;
@@ -867,10 +868,11 @@ __device__ __forceinline__ int __reduce_max_csz(int v)
 template <int NCH, int G>
 __global__ void __launch_bounds__(256) k_verify_group(VerifyArgs A, const uint32_t *dense, int64_t n_big, unsigned long long *n_ext_out)
 {
-   const int64_t th = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-   const int64_t g = th / G;
-   const int q = (int)(th % G);
-   const int lane = threadIdx.x & 63, base = lane & ~(G - 1);
+   // 64 / G entries per wave, G adjacent lanes each (G = 3: 21 entries, the last lane of the wave idle)
+   constexpr int PER_WAVE = 64 / G;
+   const int lane = threadIdx.x & 63, slot = lane / G, base = slot * G;
+   const int q = lane - base;
+   const int64_t g = ((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6) * PER_WAVE + slot;
    uint32_t steps = 0;
    unsigned long long key = ~0ull;
    int64_t p0 = 0, i = 0;
@@ -886,7 +888,7 @@ __global__ void __launch_bounds__(256) k_verify_group(VerifyArgs A, const uint32
 #pragma unroll
       for (int w = 0; w < 2 * NCH; w++) tw[p][w] = 0;
    constexpr bool KEEP_PLANES = NCH <= 3;               // (150 nt: 6.33 -> 5.38 ms for k_verify + k_verify_group; with k_verify keeping them too 5.71)
-   const bool valid = g < n_big;
+   const bool valid = slot < PER_WAVE && g < n_big;
    if (valid) { i = dense[g]; csz = (int)A.list[i].w[2]; }
    const bool mine = valid && q < csz;
    if (mine) {
