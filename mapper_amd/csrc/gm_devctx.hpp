@@ -79,6 +79,8 @@ struct gpumap_ctx {
    bool owns_text = true;
    // jump table of the leaf phases (k_build_jump): 4^jump_k entries of 16 bytes, nullptr = off
    void *d_jump = nullptr;
+   void *d_jump2 = nullptr;       // a second, shorter table for leaf blocks the first is too long for (gpumap_ann_build: the left
+   int jump2_k = 0;               // block of a k-mer is half the k-mer; 4^jump2_k entries)
    void *d_text4 = nullptr;       // the text as bit planes (k_pack_planes), built with the jump table when the text is in HBM
    int jump_k = 0;
    // launch shape
@@ -109,3 +111,4 @@ int gm_ctx_repack(gpumap_ctx *ctx, const uint64_t *d_ref_occ, const uint64_t *d_
 int gm_ctx_common_init(gpumap_ctx *ctx, int device);
 // (Re)builds the jump table for K-mers of k letters (k < 0: default for the text length; 0: none).
 int gm_ctx_build_jump(gpumap_ctx *ctx, int k);
+int gm_ctx_build_jump2(gpumap_ctx *ctx, int k);

@@ -152,6 +152,7 @@ extern "C" void gpumap_destroy(gpumap_ctx *ctx)
       if (ctx->d_sa) (void)hipFree(ctx->d_sa);
    }
    if (ctx->d_jump) (void)hipFree(ctx->d_jump);
+   if (ctx->d_jump2) (void)hipFree(ctx->d_jump2);
    if (ctx->d_text4) (void)hipFree(ctx->d_text4);
    if (ctx->d_ref_occ) (void)hipFree(ctx->d_ref_occ);
    if (ctx->d_text && ctx->owns_text) (void)hipFree(ctx->d_text);
@@ -198,6 +199,27 @@ int gm_ctx_build_jump(gpumap_ctx *ctx, int k)
       }
       HIP_TRY(hipStreamSynchronize(ctx->stream));
       ctx->jump_k = k;
+   }
+   return 0;
+failure_return:
+   return -1;
+}
+
+// The second jump table (k letters, 0 = none): for searches whose leaf blocks are shorter than the first table's
+// letters (gpumap_ann_build).  Kept until the context goes or another length is asked for.
+int gm_ctx_build_jump2(gpumap_ctx *ctx, int k)
+{
+   if (k == ctx->jump2_k) return 0;
+   if (ctx->d_jump2) { HIP_TRY(hipFree(ctx->d_jump2)); ctx->d_jump2 = nullptr; ctx->jump2_k = 0; }
+   if (k <= 0) return 0;
+   GM_FAIL_IF(k > 13, "jump2_k out of range.");
+   {
+      const int64_t entries = (int64_t)1 << (2 * k);
+      HIP_TRY(hipMalloc(&ctx->d_jump2, 16 * (size_t)entries));
+      hipLaunchKernelGGL(k_build_jump, dim3((unsigned)cdiv(entries, 256)), dim3(256), 0, ctx->stream, ctx->ix, k, (int64_t)0, (uint4 *)ctx->d_jump2);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      ctx->jump2_k = k;
    }
    return 0;
 failure_return:
@@ -905,7 +927,8 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
          hipLaunchKernelGGL(k_sc_prepare, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, st, ctx->ix, b->reads.as<const uint8_t>(),
                             b->read_len.as<const uint16_t>(), b->len_row.as<const uint16_t>(), b->row_state.as<const uint8_t>(), R,
                             b->stride, tau, b->read_row.as<uint16_t>(), b->sc_bound.as<int64_t>(), b->score_add.as<uint8_t>(),
-                            b->status.as<int64_t>(), b->sc_qfp.as<int64_t>(), b->sc_qrp.as<int64_t>());
+                            b->status.as<int64_t>(), b->sc_qfp.as<int64_t>(), b->sc_qrp.as<int64_t>(),
+                            (const uint4 *)ctx->d_jump, ctx->jump_k, (const uint4 *)ctx->d_jump2, ctx->jump2_k);
          HIP_TRY(hipGetLastError());
       } else if (R > 0) {
          hipLaunchKernelGGL(k_status, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, st, b->read_len.as<const uint16_t>(),
@@ -963,6 +986,7 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
          A.cursor = cnt + 0; A.hits = b->hits.as<Node>(); A.hit_cap = hit_cap; A.hit_count = cnt + 1; A.n_ext = cnt + 2;
          A.spill = b->spill.as<Node>(); A.spill_cap = (uint32_t)ctx->spill_cap; A.error = (int *)(cnt + 3); A.stats = cnt + 4;
          A.jump = (const uint4 *)ctx->d_jump; A.jump_k = ctx->jump_k;
+         A.jump2 = (const uint4 *)ctx->d_jump2; A.jump2_k = ctx->jump2_k;
          A.verify = use_verify;
          A.verify_stable = 1;
          A.read_row = sc ? b->read_row.as<const uint16_t>() : nullptr;
@@ -1561,6 +1585,15 @@ extern "C" int gpumap_ann_build(gpumap_ctx *ctx, int kmer, int tau, uint8_t *tab
    GM_FAIL_IF(ctx->d_text == nullptr, "the context holds no text.");
    HIP_TRY(hipSetDevice(ctx->device));
    {
+      // The left block of a k-mer (src/blocksearch.c:69-70) is searched exactly, in (tau / 2 + 1) leaf blocks at most:
+      // where the context's jump table is longer than those, a second one of their length stands in for their steps
+      // (k = 25, tau 1: 11 of about 40 steps per k-mer).
+      const int leaf = (kmer / 2) / (tau / 2 + 1);
+      const int k2 = std::min(leaf - 1, 12);
+      const bool fits = k2 >= 8 && ((int64_t)1 << (2 * k2)) <= ctx->ix.n && !(getenv("GPUMAP_ANN_JUMP2") && atoi(getenv("GPUMAP_ANN_JUMP2")) == 0);
+      if (fits && (ctx->jump_k == 0 || ctx->jump_k > k2)) GM_FAIL_IF(gm_ctx_build_jump2(ctx, k2) != 0, "cannot build the second jump table.");
+   }
+   {
       const int64_t n = ctx->ix.n, half = n / 2;
       const uint8_t *text = (const uint8_t *)ctx->d_text;
       hipStream_t st = ctx->stream;
@@ -1605,9 +1638,9 @@ extern "C" int gpumap_ann_build(gpumap_ctx *ctx, int kmer, int tau, uint8_t *tab
       const int64_t chunk = getenv("GPUMAP_ANN_CHUNK") ? std::max<int64_t>(1, atoll(getenv("GPUMAP_ANN_CHUNK"))) : ((int64_t)1 << 22);   // (interval output: < 2^24 queries per batch)
       for (int64_t c0 = 0; c0 < n_q; c0 += chunk) {
          const int64_t nq = std::min(chunk, n_q - c0);
-         HIP_TRY(codes.ensure((size_t)nq * (size_t)kmer));
+         HIP_TRY(codes.ensure((size_t)nq * (size_t)kmer + 4));
          HIP_TRY(offs.ensure(8 * (size_t)(nq + 1)));
-         hipLaunchKernelGGL(k_ann_gather, dim3((unsigned)cdiv(nq + 1, 256)), dim3(256), 0, st, ctx->ix, text, q_sa.as<const int64_t>() + c0, nq,
+         hipLaunchKernelGGL(k_ann_gather, dim3((unsigned)cdiv(std::max<int64_t>(nq + 1, cdiv(nq * kmer, 4)), 256)), dim3(256), 0, st, ctx->ix, text, q_sa.as<const int64_t>() + c0, nq,
                             kmer, codes.as<uint8_t>(), offs.as<int64_t>());
          HIP_TRY(hipGetLastError());
          HIP_TRY(hipStreamSynchronize(st));               // (the batch works on a stream of its own)

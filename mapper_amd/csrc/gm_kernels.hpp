@@ -348,6 +348,8 @@ struct SearchArgs {
                                 // [4] chunks of SPILL_CHUNK nodes that deques moved to their spill regions
    const uint4 *jump;           // jump table (k_build_jump) or nullptr
    int jump_k;
+   const uint4 *jump2;          // a shorter table for the leaves `jump` is too long for, or nullptr
+   int jump2_k;
    int verify;                  // nodes with sz <= verify (0, 1, 2 or 4) leave as candidates for k_verify
    int verify_stable;           // 1: those of more than two suffixes only when the last step left the interval as it was
    uint32_t cursor_chunk;       // reads a wave reserves per atomic on the cursor (a multiple of its refill)
@@ -367,7 +369,8 @@ struct SearchArgs {
 __global__ void __launch_bounds__(256) k_sc_prepare(IndexDev ix, const uint8_t *reads, const uint16_t *read_len, const uint16_t *len_row,
                                                     const uint8_t *row_state, int64_t n_reads, int stride, int tau,
                                                     uint16_t *read_row, int64_t *sc_bound, uint8_t *score_add, int64_t *status,
-                                                    int64_t *q_fp, int64_t *q_rp /* the interval of the whole query (path[kmer] of ann_build_mt) */)
+                                                    int64_t *q_fp, int64_t *q_rp /* the interval of the whole query (path[kmer] of ann_build_mt) */,
+                                                    const uint4 *jump, int jump_k, const uint4 *jump2, int jump2_k)
 {
    const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
    if (r >= n_reads) return;
@@ -381,7 +384,40 @@ __global__ void __launch_bounds__(256) k_sc_prepare(IndexDev ix, const uint8_t *
    int64_t end_lo = 0, end_hi = 0;                                     // fp + sz after m/2 and after m/2 + m%2 letters
    int n_cnt = 0;
    const int cut_lo = m / 2, cut_hi = m / 2 + m % 2;
-   for (int i = 0; i < m; i++) {
+   // The bi-interval of a prefix q[0, K) without N that occurs in the text is what the jump tables hold for that string
+   // (k_build_jump reaches it letter by letter from the other end): one look-up stands in for K steps of the path,
+   // once below the first cut and once behind the second.
+   auto look_up = [&](int at_most, int more_than) {
+      const uint4 *jt = nullptr;
+      int K = 0;
+      if (jump != nullptr && jump_k <= at_most && jump_k > more_than) { jt = jump; K = jump_k; }
+      if (jump2 != nullptr && jump2_k <= at_most && jump2_k > more_than && jump2_k > K) { jt = jump2; K = jump2_k; }
+      if (jt == nullptr) return 0;
+      uint32_t idx = 0, bad = 0;
+      for (int t = 0; t < K; t++) {
+         const uint32_t sym = q[K - 1 - t];
+         bad |= sym & ~3u;
+         idx |= (sym & 3u) << (2 * t);
+      }
+      if (bad) return 0;
+      const uint4 e = jt[idx];
+      const int64_t esz = (int64_t)e.z | ((int64_t)((e.w >> 16) & 0xff) << 32);
+      if (esz < 1) return 0;                         // (an absent prefix: the path's own pointers are wanted)
+      fp = (int64_t)e.x | ((int64_t)(e.w & 0xff) << 32);
+      rp = (int64_t)e.y | ((int64_t)((e.w >> 8) & 0xff) << 32);
+      sz = esz;
+      return K;
+   };
+   int i = look_up(cut_lo, 0);
+   if (i > 0 && i == cut_lo) end_lo = fp + sz;
+   if (i > 0 && i == cut_hi) end_hi = fp + sz;
+   bool second = false;
+   while (i < m) {
+      if (!second && i >= cut_hi) {
+         second = true;
+         const int K = look_up(m, i);
+         if (K > 0) { i = K; continue; }
+      }
       const int s = q[i];
       n_cnt += s == UNKNOWN;
       int64_t occ0[SYMS], occ1[SYMS], fpn[SYMS], rpn[SYMS], szn[SYMS];
@@ -391,8 +427,9 @@ __global__ void __launch_bounds__(256) k_sc_prepare(IndexDev ix, const uint8_t *
       extend_all(fp, sz, occ0, occ1, c, fpn, rpn, szn);
       const int js = complement(s);
       fp = rpn[js]; rp = fpn[js]; sz = szn[js];
-      if (i + 1 == cut_lo) end_lo = fp + sz;
-      if (i + 1 == cut_hi) end_hi = fp + sz;
+      i++;
+      if (i == cut_lo) end_lo = fp + sz;
+      if (i == cut_hi) end_hi = fp + sz;
    }
    const int last = fp >= rp;                                           // :55
    q_fp[r] = fp; q_rp[r] = rp;

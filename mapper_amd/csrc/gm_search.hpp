@@ -244,21 +244,25 @@ __global__ void __launch_bounds__(WG_THREADS) k_search(SearchArgs A)
                         // The first K steps of a leaf are an exact search from the root interval: one look-up in
                         // the jump table instead (counted as the steps the reference executes).  Not for a query N
                         // among the K symbols (it follows all symbols), nor when the block has no letter left after.
-                        if (A.jump != nullptr && sd.pos - sd.end >= A.jump_k) {
+                        const uint4 *jt = nullptr;
+                        int jk = 0;
+                        if (A.jump != nullptr && sd.pos - sd.end >= A.jump_k) { jt = A.jump; jk = A.jump_k; }
+                        else if (A.jump2 != nullptr && sd.pos - sd.end >= A.jump2_k) { jt = A.jump2; jk = A.jump2_k; }
+                        if (jt != nullptr) {
                            const uint8_t *qp = A.reads + (size_t)rd * A.stride + sd.pos;
                            uint32_t idx = 0, bad = 0;
-                           for (int t = 0; t < A.jump_k; t++) {
+                           for (int t = 0; t < jk; t++) {
                               const uint32_t sym = qp[-t];
                               bad |= sym & ~3u;
                               idx |= (sym & 3u) << (2 * t);
                            }
                            if (!bad) {
-                              const uint4 e = A.jump[idx];
+                              const uint4 e = jt[idx];
                               sd.fp = (int64_t)e.x | ((int64_t)(e.w & 0xff) << 32);
                               sd.rp = (int64_t)e.y | ((int64_t)((e.w >> 8) & 0xff) << 32);
                               sd.sz = (int64_t)e.z | ((int64_t)((e.w >> 16) & 0xff) << 32);
                               jump_steps += e.w >> 24;
-                              sd.pos -= A.jump_k;
+                              sd.pos -= jk;
                               mk = sd.sz > 0;
                            }
                         }
