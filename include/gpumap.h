@@ -379,7 +379,7 @@ int gpumap_mapper_multi(const char *qfile, const gpumap_index *index, gpumap_ctx
 **   "verify"         0 = every step on the Occ table; 1 = nodes of one suffix are finished on the text;
 **                    2 = also nodes of two suffixes; 4 = also nodes of three and four; 8 / 16 = also nodes of up to
 **                    eight / sixteen (measured slower than 4 at GRCh38 size); -1 = by the size of the text (the
-**                    default: 4 from 2^31 symbols on, else 1)
+**                    default: 4 from 2^26 symbols on, else 1)
 **   "sort_all_bits"  1 = the sort of the located hits runs over every bit of the keys (default 0: it leaves out the
 **                    score and up to three low bits of the position where that saves a pass; short runs are ordered after)
 **   "verify_tile"    entries of the search's output list a workgroup of k_verify takes (0 = the default, 512; at most 1024) */

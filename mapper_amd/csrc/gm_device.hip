@@ -963,7 +963,7 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
       // -1 (default): 4 for texts of 2^31 symbols and more, else 1 (measured: pairs and groups pay where most k-mers
       // of the jump table's length occur more than once; at GRCh38 size 22.6 -> 21.0 ms per batch with pairs,
       // 19.1 -> 18.0 with groups; pairs cost 13 % at chr21 size)
-      const int verify_mode = ctx->verify >= 0 ? ctx->verify : (ctx->ix.n >= ((int64_t)1 << 31) ? 4 : 1);
+      const int verify_mode = ctx->verify >= 0 ? ctx->verify : (ctx->ix.n >= ((int64_t)1 << 26) ? 4 : 1);
       const int use_verify = (verify_mode && ctx->d_text != nullptr && ctx->d_text4 != nullptr && !want_intervals && !sc) ? verify_mode : 0;
       // first guess of the list's length (a batch that is run or refilled again keeps the longer list): with
       // k_verify every seed can leave a candidate, plus what repeats add (5.5 entries per read at GRCh38
