@@ -238,7 +238,9 @@ __global__ void __launch_bounds__(256) k_encode(const uint8_t *src, const int64_
    const int gpr = stride >> 5;                                   // groups of 32 symbols per row
    // grid-stride: a launch holds fewer than 2^32 threads
    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n_reads * gpr; t += (int64_t)gridDim.x * blockDim.x) {
-      const int64_t r = t / gpr;
+      // (stride is a multiple of 128: gpr is 4, 8, 12, ...; a shift where it is a power of two, a 32-bit division
+      // where the batch allows it: the 64-bit division was a third of the kernel's instructions)
+      const int64_t r = (gpr & (gpr - 1)) == 0 ? t >> (31 - __clz(gpr)) : (t < ((int64_t)1 << 32) ? (int64_t)((uint32_t)t / (uint32_t)gpr) : t / gpr);
       const int g = (int)(t - r * gpr);
       const int64_t beg = offsets[r], len = offsets[r + 1] - beg;
       int64_t k64 = len - 32 * (int64_t)g;
