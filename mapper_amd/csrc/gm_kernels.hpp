@@ -381,7 +381,18 @@ __global__ void __launch_bounds__(256) k_sc_prepare(IndexDev ix, const uint8_t *
    if (m < 1 || m > MAX_READ) { status[r] = -1; return; }             // :37; longer than the mismatch bitmap (src/blocksearch.h:12-13)
    uint64_t c[SYMS];
    for (int j = 0; j < SYMS; j++) c[j] = ix.tables[TAB_C + j];
-   const uint8_t *q = reads + r * stride;
+   const uint8_t *qrow = reads + r * stride;
+   // the letters of a query of up to 32 come as two 16-byte loads, kept as nibbles (a byte load per letter and lane, each
+   // lane on a row of its own, is a trip through the address unit per letter)
+   uint64_t nib0 = 0, nib1 = 0;
+   if (m <= 32) {
+      const uint4 *q16 = reinterpret_cast<const uint4 *>(qrow);
+      const uint4 a4 = q16[0], b4 = q16[1];
+      auto squeeze = [](uint32_t w) { uint32_t x = w & 0x0f0f0f0fu; x = (x | (x >> 4)) & 0x00ff00ffu; return (uint64_t)((x | (x >> 8)) & 0xffffu); };
+      nib0 = squeeze(a4.x) | (squeeze(a4.y) << 16) | (squeeze(a4.z) << 32) | (squeeze(a4.w) << 48);
+      nib1 = squeeze(b4.x) | (squeeze(b4.y) << 16) | (squeeze(b4.z) << 32) | (squeeze(b4.w) << 48);
+   }
+   auto q = [&](int i) -> int { return m <= 32 ? (int)(((i < 16 ? nib0 : nib1) >> (4 * (i & 15))) & 15u) : (int)qrow[i]; };
    int64_t fp = 0, rp = 0, sz = ix.n;                                  // bwt_new_query
    int64_t end_lo = 0, end_hi = 0;                                     // fp + sz after m/2 and after m/2 + m%2 letters
    int n_cnt = 0;
@@ -397,7 +408,7 @@ __global__ void __launch_bounds__(256) k_sc_prepare(IndexDev ix, const uint8_t *
       if (jt == nullptr) return 0;
       uint32_t idx = 0, bad = 0;
       for (int t = 0; t < K; t++) {
-         const uint32_t sym = q[K - 1 - t];
+         const uint32_t sym = (uint32_t)q(K - 1 - t);
          bad |= sym & ~3u;
          idx |= (sym & 3u) << (2 * t);
       }
@@ -420,7 +431,7 @@ __global__ void __launch_bounds__(256) k_sc_prepare(IndexDev ix, const uint8_t *
          const int K = look_up(m, i);
          if (K > 0) { i = K; continue; }
       }
-      const int s = q[i];
+      const int s = q(i);
       n_cnt += s == UNKNOWN;
       int64_t occ0[SYMS], occ1[SYMS], fpn[SYMS], rpn[SYMS], szn[SYMS];
       // bwt_query(s, BWT_QUERY_SUFFIX): the backward step on the reverse complement's side (src/index_bwt.c:234-238, :280-286)
