@@ -1171,7 +1171,7 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
       // a short list of entries, else every entry of the list) get their slots by a scan of their sizes and read
       // their suffix-array entries
       const int64_t H = b->n_hits;
-      const int64_t n_look = verified ? n_iv : H;              // entries the interval path looks at
+      const int64_t n_look = (result_flags & GM_RUN_NO_LOCATE) ? 0 : (verified ? n_iv : H);      // entries the interval path looks at
       const uint32_t *dense = verified ? b->iv_dense.as<const uint32_t>() : (const uint32_t *)nullptr;
       int64_t L_iv = 0;
       HIP_TRY(b->read_first.ensure(8 * (size_t)(R + 1)));
@@ -1645,7 +1645,7 @@ extern "C" int gpumap_ann_build(gpumap_ctx *ctx, int kmer, int tau, uint8_t *tab
          HIP_TRY(hipGetLastError());
          HIP_TRY(hipStreamSynchronize(st));               // (the batch works on a stream of its own)
          GM_FAIL_IF(gm_batch_fill(ctx, b, codes.p, offs.as<const int64_t>(), nq, GM_SRC_DEVICE, false) != 0, "cannot stage the k-mers.");
-         GM_FAIL_IF(gm_batch_run(ctx, b, tau, 1, GM_RUN_SC) != 0, "the search of the k-mers failed.");
+         GM_FAIL_IF(gm_batch_run(ctx, b, tau, 1, GM_RUN_SC | GM_RUN_NO_LOCATE) != 0, "the search of the k-mers failed.");
          const int64_t H = b->n_real, U = H + nq;
          n_ext += b->n_ext; n_hits += H; n_updates += U;
          for (DevBuf *x : {&ukey, &ukey2, &uval, &uval2}) HIP_TRY(x->ensure(8 * (size_t)U));

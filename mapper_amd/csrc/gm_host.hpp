@@ -90,7 +90,8 @@ int gm_host_threads();     // worker threads of the host stages: GPUMAP_HOST_THR
 
 // Internal forms of the batch calls (gm_device.hip), used by the pipeline (gm_pipe.cpp): the public entry points
 // derive the flags from the context's options, the pipeline brings its own.
-constexpr int GM_RESULT_PINNED = 1, GM_RESULT_COMPACT = 2, GM_RESULT_ONE_ARENA = 4, GM_RUN_SC = 8;
+constexpr int GM_RESULT_PINNED = 1, GM_RESULT_COMPACT = 2, GM_RESULT_ONE_ARENA = 4, GM_RUN_SC = 8,
+              GM_RUN_NO_LOCATE = 16;      // gm_batch_run: interval hits only (gpumap_ann_build), no located hits
 constexpr int GM_SRC_TEXT = GPUMAP_SRC_TEXT, GM_SRC_DEVICE = GPUMAP_SRC_DEVICE;
 int gm_batch_fill(gpumap_ctx *ctx, gpumap_batch *b, const void *src, const int64_t *offsets, int64_t n_reads, int src_flags, bool encode_now);
 int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, int result_flags);
