@@ -346,7 +346,9 @@ void          gpumap_multi_destroy(gpumap_multi *multi);
 ** reuses the search of another k-mer: every k-mer is searched afresh here, what blocksc_trail
 ** computes with trail = 0.  Needs a context that holds the text; 17 bytes of device memory per symbol of the text
 ** beside the index.  stats (may be NULL):
-** [0] k-mers searched, [1] extension steps, [2] hits, [3] updates of records, [4] microseconds on the device.
+** [0] k-mers searched, [1] extension steps, [2] hits, [3] updates of records, [4] microseconds on the device,
+** [5] letters of the second jump table the build put in place for the k-mers' left blocks (0: none; it stays with the
+** context and also serves reads whose leaf blocks the first table is too long for).
 ** gpumap_ann_query = ann_query (:278-347) on such a table (align_pos: room for kmer entries, may be NULL);
 ** gpumap_ann_file_write = ann_file_write (:384-434): the file index_read picks up as <base>.ann.<kmer>.<tau>.
 ** ---------------------------------------------------------------------------------------- */

@@ -545,7 +545,7 @@ class Context:
         if lib().gpumap_ann_build(self._h, kmer, tau, _ptr(table), _ptr(stats)) != 0:
             raise GpumapError("gpumap_ann_build failed (see stderr)")
         return table, {"queries": int(stats[0]), "n_ext": int(stats[1]), "hits": int(stats[2]), "updates": int(stats[3]),
-                       "us": int(stats[4])}
+                       "us": int(stats[4]), "jump2_k": int(stats[5])}
 
     def query_all_noalloc(self, end, fp, rp, sz):
         """gpumap_query_all_noalloc: at most NOALLOC_MAX_QUERIES intervals, staged in the library's static scratch."""

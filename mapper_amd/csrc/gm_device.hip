@@ -1694,7 +1694,8 @@ extern "C" int gpumap_ann_build(gpumap_ctx *ctx, int kmer, int tau, uint8_t *tab
       (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
       if (stats) {
          stats[0] = n_q; stats[1] = n_ext; stats[2] = n_hits; stats[3] = n_updates; stats[4] = (int64_t)(1000.0f * ms);
-         stats[5] = stats[6] = stats[7] = 0;
+         stats[5] = ctx->jump2_k;                      // letters of the second jump table in place (0: none)
+         stats[6] = stats[7] = 0;
       }
    }
    rc = 0;

@@ -58,3 +58,28 @@ def test_ann_bad_arguments(workdir):
         with pytest.raises(ma.GpumapError):
             ctx.ann_build(k, tau)
     ctx.close()
+
+
+def test_second_jump_table_changes_nothing(workdir, monkeypatch):
+    """Where the context's jump table is longer than the left block of a k-mer, gpumap_ann_build builds a second one of the
+    block's length (gm_ctx_build_jump2) that stands in for the block's exact steps in k_search<true> and for prefixes of
+    the path of k_sc_prepare: the same table, k-mers and extension steps as without it; and reads whose leaf blocks only
+    the second table fits map as the oracle says (located hits and extension steps) while it is in place."""
+    from mapper_amd import synth
+    base, seqs = common.synth_index(workdir, "ann2m", 2_200_000, seed=43, n_seqs=2, repeat_rich=True)
+    ctx = ma.Context.from_files(base, 0)
+    ctx.set_option("jump_k", 12)                       # longer than the 12 or 13 letters of a 25-mer's left block allow
+    monkeypatch.setenv("GPUMAP_ANN_JUMP2", "0")
+    want, st0 = ctx.ann_build(25, 1)
+    monkeypatch.delenv("GPUMAP_ANN_JUMP2")
+    got, st1 = ctx.ann_build(25, 1)                    # builds the table of 11 letters (4^11 <= the text's length)
+    assert np.array_equal(got, want)
+    assert st0["jump2_k"] == 0 and st1["jump2_k"] == 11
+    assert (st0["queries"], st0["n_ext"], st0["hits"]) == (st1["queries"], st1["n_ext"], st1["hits"])
+    assert np.count_nonzero(got) > 1000
+    codes, offs = synth.make_reads(seqs, 3000, 36, 2, seed=44, n_frac=0.01)
+    d = po.Index(base).map_batch(codes.reshape(-1), offs, 2, threads=8)
+    h = ctx.map_batch(codes.reshape(-1), offs, 2)
+    assert np.array_equal(h.located(), d.located())
+    assert h.n_ext == d.n_ext
+    ctx.close()
