@@ -1591,7 +1591,8 @@ extern "C" int gpumap_ann_build(gpumap_ctx *ctx, int kmer, int tau, uint8_t *tab
       const int leaf = (kmer / 2) / (tau / 2 + 1);
       const int k2 = std::min(leaf - 1, 12);
       const bool fits = k2 >= 8 && ((int64_t)1 << (2 * k2)) <= ctx->ix.n && !(getenv("GPUMAP_ANN_JUMP2") && atoi(getenv("GPUMAP_ANN_JUMP2")) == 0);
-      if (fits && ctx->jump_k > k2) GM_FAIL_IF(       // (jump_k = 0: the tables are switched off, or the text is too short for any)gm_ctx_build_jump2(ctx, k2) != 0, "cannot build the second jump table.");
+      // (jump_k = 0: the tables are switched off, or the text is too short for any)
+      if (fits && ctx->jump_k > k2) GM_FAIL_IF(gm_ctx_build_jump2(ctx, k2) != 0, "cannot build the second jump table.");
    }
    {
       const int64_t n = ctx->ix.n, half = n / 2;
