@@ -1233,7 +1233,8 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
          const int end_bit = pos_bits + 4 + read_bits;
          int begin_bit = 0;
          for (int drop = 0; drop <= 3 && begin_bit == 0; drop++)
-            if (cdiv(end_bit - (4 + drop), 8) < cdiv(end_bit, 8) && !ctx->sort_all_bits) begin_bit = 4 + drop;
+            if (cdiv(end_bit - (4 + drop), 8) < cdiv(end_bit, 8) && !ctx->sort_all_bits && end_bit < 64) begin_bit = 4 + drop;   // (end_bit = 64 with
+                                                                          // begin_bit > 0: hipcub returns unsorted keys for 10^4 .. 10^6 items, tools/sortpairs_check.hip)
          HIP_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp, db, (int)L, begin_bit, end_bit, st));
          HIP_TRY(b->cub_tmp.ensure(tmp));
          HIP_TRY(hipcub::DeviceRadixSort::SortKeys(b->cub_tmp.p, tmp, db, (int)L, begin_bit, end_bit, st));
@@ -1254,7 +1255,7 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
          HIP_TRY(hipGetLastError());
       }
       if (want_intervals && H > 0) {
-         GM_FAIL_IF(R >= ((int64_t)1 << 24), "interval output supports at most 2^24 reads per batch.");
+         GM_FAIL_IF(R >= ((int64_t)1 << 24) - 1, "interval output supports fewer than 2^24 - 1 reads per batch.");
          GM_FAIL_IF(H >= ((int64_t)1 << 31), "too many interval hits in one batch.");
          HIP_TRY(b->hkeys.ensure(8 * (size_t)H)); HIP_TRY(b->hkeys_alt.ensure(8 * (size_t)H));
          HIP_TRY(b->hidx.ensure(4 * (size_t)H)); HIP_TRY(b->hidx_alt.ensure(4 * (size_t)H));
@@ -1263,9 +1264,13 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
          hipcub::DoubleBuffer<unsigned long long> dk(b->hkeys.as<unsigned long long>(), b->hkeys_alt.as<unsigned long long>());
          hipcub::DoubleBuffer<unsigned int> dv(b->hidx.as<unsigned int>(), b->hidx_alt.as<unsigned int>());
          size_t tmp = 0;
-         HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, dk, dv, (int)H, 0, 64, st));
+         // gpumap_ann_build (GM_RUN_NO_LOCATE) only needs the hits of a query together, in any order: the query's bits alone,
+         // 3 passes instead of 8 (end_bit 63, not 64: see k_hit_keys)
+         const bool by_query = (result_flags & GM_RUN_NO_LOCATE) != 0;
+         const int sort_lo = by_query ? 39 : 0, sort_hi = by_query ? 63 : 64;
+         HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, dk, dv, (int)H, sort_lo, sort_hi, st));
          HIP_TRY(b->cub_tmp.ensure(tmp));
-         HIP_TRY(hipcub::DeviceRadixSort::SortPairs(b->cub_tmp.p, tmp, dk, dv, (int)H, 0, 64, st));
+         HIP_TRY(hipcub::DeviceRadixSort::SortPairs(b->cub_tmp.p, tmp, dk, dv, (int)H, sort_lo, sort_hi, st));
          for (DevBuf *x : {&b->hit_read, &b->hit_fp, &b->hit_rp, &b->hit_sz, &b->hit_dp, &b->hit_score}) HIP_TRY(x->ensure(8 * (size_t)H));
          HIP_TRY(b->hit_align.ensure(32 * (size_t)H));
          // the holes of the list sorted last: the first n_real entries are the hits

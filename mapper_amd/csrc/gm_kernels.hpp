@@ -1202,8 +1202,10 @@ __global__ void k_hit_keys(const Node *hits, int64_t n_hits, unsigned long long 
    if (i >= n_hits) return;
    NodeR h;
    unpack_node(hits[i], h);
-   // reads < 2^24 per run, fp < 2^40; holes of the list (sz = 0) sort behind every hit
-   keys[i] = h.sz > 0 ? (((unsigned long long)h.read << 40) | (unsigned long long)h.fp) : ~0ull;
+   // reads < 2^24 - 1 per run, fp < 2^39 (n < 2^34); holes of the list (sz = 0) sort behind every hit, also where only the
+   // bits [39, 63) are sorted (gpumap_ann_build; not [40, 64): hipcub's radix sort with begin_bit > 0 and end_bit = 64
+   // returns unsorted keys for 10^4 .. 10^6 items on this ROCm, tools/sortpairs_check.hip)
+   keys[i] = h.sz > 0 ? (((unsigned long long)h.read << 39) | (unsigned long long)h.fp) : ~0ull;
    idx[i] = (unsigned int)i;
 }
 
