@@ -192,7 +192,7 @@ typedef struct {
 
    /* Interval hits = content of tree->stack after blocksearch_trail_rec (spath_t,
    ** src/blocksearch.h:16-20), sorted by (read, fp) (the reference's order is the order of its depth-first
-   ** search; the sets are equal).  Filled when want_intervals != 0; at most 2^24 reads per batch then. */
+   ** search; the sets are equal).  Filled when want_intervals != 0; fewer than 2^24 - 1 reads per batch then. */
    int64_t   n_hits;
    int64_t  *hit_read, *hit_fp, *hit_rp, *hit_sz, *hit_dp, *hit_score;   /* [n_hits] */
    uint64_t *hit_align;       /* [n_hits][GPUMAP_ALIGN_WORDS] mismatch + query-N bitmap */
