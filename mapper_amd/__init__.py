@@ -537,15 +537,19 @@ class Context:
             raise GpumapError("gpumap_prefix_all failed")
         return out
 
-    def ann_build(self, kmer, tau):
-        """gpumap_ann_build: the annotation table (txt_len / 2 bytes) and the work figures."""
+    def ann_build(self, kmer, tau, threads=1, trail_reuse=True):
+        """gpumap_ann_build: the annotation table (txt_len / 2 bytes) and the work figures.  threads = the `threads` of the
+        reference's ann_build whose job list is reproduced; trail_reuse = with the reference's reuse of the last k-mer's
+        search (False: every k-mer searched afresh)."""
+        self.set_option("ann_threads", threads)
+        self.set_option("ann_trail_reuse", 1 if trail_reuse else 0)
         txt_len = int(self.export()[1][:16].view(np.int64)[1])        # (the header of an exported index: magic, n, ...)
         table = np.zeros(txt_len // 2, dtype=np.uint8)
         stats = np.zeros(8, dtype=np.int64)
         if lib().gpumap_ann_build(self._h, kmer, tau, _ptr(table), _ptr(stats)) != 0:
             raise GpumapError("gpumap_ann_build failed (see stderr)")
         return table, {"queries": int(stats[0]), "n_ext": int(stats[1]), "hits": int(stats[2]), "updates": int(stats[3]),
-                       "us": int(stats[4]), "jump2_k": int(stats[5])}
+                       "us": int(stats[4]), "jump2_k": int(stats[5]), "split": int(stats[6])}
 
     def query_all_noalloc(self, end, fp, rp, sz):
         """gpumap_query_all_noalloc: at most NOALLOC_MAX_QUERIES intervals, staged in the library's static scratch."""

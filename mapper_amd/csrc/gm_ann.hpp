@@ -80,13 +80,22 @@ __device__ __forceinline__ uint64_t ann_fold(uint64_t x, uint64_t y)
 
 // One thread per suffix-array entry, entries first .. last - 1 (a launch of 2^32 threads and more is cut short by the
 // runtime without an error: the host launches pieces).
-__global__ void __launch_bounds__(256) k_ann_classify(IndexDev ix, const uint8_t *text, int kmer, int tau, uint8_t *cls, int64_t first, int64_t last)
+// depth = letters of the prefixes the reference cuts its jobs at (:116-121: 1 for threads = 1, the smallest d with
+// 5^d >= 5 * threads): a job is the interval of one prefix of `depth` symbols with at most tau N (jobs_by_prefix,
+// :612-661); suffixes with a separator or more than tau N among their first `depth` symbols lie in no job.
+__global__ void __launch_bounds__(256) k_ann_classify(IndexDev ix, const uint8_t *text, int kmer, int tau, int depth, uint8_t *cls, int64_t first, int64_t last)
 {
    const int64_t i = first + blockIdx.x * (int64_t)256 + threadIdx.x;
    if (i >= last) return;
    const int64_t p = sa_entry(ix.sa, ix.sar_bits, i);
    uint8_t c = ANN_CLS_NONE;
-   if (text[p] < SYMS) {                                  // the jobs cover the suffixes that start with one of the five symbols (:116-132, threads = 1)
+   bool in_job = p + depth <= ix.n;
+   {
+      int n_head = 0;
+      for (int t = 0; in_job && t < depth; t++) { const int s = text[p + t]; in_job = s < SYMS; n_head += s == UNKNOWN; }
+      in_job = in_job && n_head <= tau;                   // :629
+   }
+   if (in_job) {                                          // the jobs cover the suffixes that start with one of the five symbols (:116-132, threads = 1)
       bool valid = p + kmer <= ix.n;                      // :765
       int n_cnt = 0;
       for (int t = 0; valid && t < kmer; t++) {           // :773-777
@@ -128,6 +137,162 @@ __global__ void __launch_bounds__(256) k_ann_gather(IndexDev ix, const uint8_t *
       if (++off == kmer && b0 + k + 1 < total) { off = 0; q++; p = sa_entry(ix.sa, ix.sar_bits, q_sa[q]); }
    }
    reinterpret_cast<uint32_t *>(codes)[t] = word;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The reference's reuse of the last k-mer's search (`trail`: src/index_ann.c:552-570, src/blocksearch.c:41-43, :63-66,
+// :73-86, :156-157).  ann_build_mt keeps, per job and strand class, the last k-mer it searched (query_1 / query_2) and a
+// tree of hit stacks; blocksc_trail recomputes tree->next_l->stack (the hits of the left block, filtered by the bound)
+// only when the new k-mer shares fewer than pos_r letters with the last one, and blocksearch_trail_rec recomputes the
+// leaf tree->next_l->next_l->stack only when it shares fewer than the leaf's length.  A k-mer whose search returns early
+// (:63-66) replaces the last k-mer but leaves the tree as it is, and a k-mer with N runs its left block with a smaller
+// budget: the next k-mer then extends hits that were made for other letters or another budget.  Where no k-mer of the
+// text holds an N none of this shows (every reuse is of hits that a fresh search would find again); where some do, the
+// reference's table is what this plan reproduces: per k-mer of a chunk, in suffix-array order,
+//    prev   the last k-mer of its class before it                                     (inclusive scan, shifted)
+//    trail  the letters it shares with prev (0 across a job's border: the state is per job)
+//    wl     it recomputes the left block's hits (searched and trail < pos_r); wll: it recomputes the first leaf
+//    ol     the last k-mer of its class up to itself with wl; oll: the same with wll   (inclusive scans)
+// and the search of k-mer i is run as the reference's state has it: letters [0, pos_r) and the left block's budget and
+// bound of ol, the first leaf's letters of oll where that leaf is searched on its own, the extension's letters and
+// budget of i.  Steps are counted where the reference executes them (not in blocks it took from the tree).  The state
+// that crosses from one chunk of k-mers to the next is AnnCarry.
+// ------------------------------------------------------------------------------------------------
+struct AnnCarry {
+   int64_t prev[2];          // per strand class: index (in the list of all k-mers) of the last k-mer of the class, -1 = none
+   int64_t ol[2];            // of the k-mer whose left block's hits the tree holds
+   int64_t ol_bound[2];      // its bound (:76) and
+   int64_t oll[2];           // of the k-mer whose first leaf's hits the tree holds
+   int32_t ol_tl[2];         // the budget of its left block (:70)
+};
+
+struct AnnPlanArgs {
+   IndexDev ix;
+   const uint8_t *text;
+   const int64_t *q_sa;      // the suffix-array entries of ALL k-mers searched, in order
+   int64_t c0, nq;           // the chunk: k-mers c0 .. c0 + nq - 1 are queries 0 .. nq - 1 of the batch
+   int kmer, tau, depth, stride, n_nat;
+   const int64_t *q_fp, *q_rp;
+   uint8_t *reads;           // the batch's arrays, with room for 2 * nq queries
+   uint16_t *read_len, *read_row;
+   int64_t *sc_bound;
+   uint8_t *score_add, *sc_flags;
+   uint32_t *alias;
+   unsigned long long *s1, *s2a, *s2b;
+   AnnCarry *carry;
+   unsigned int *n_extra;
+};
+
+struct MaxHalves {
+   __host__ __device__ unsigned long long operator()(unsigned long long a, unsigned long long b) const
+   {
+      const unsigned long long lo = (a & 0xffffffffull) > (b & 0xffffffffull) ? (a & 0xffffffffull) : (b & 0xffffffffull);
+      const unsigned long long hi = (a >> 32) > (b >> 32) ? (a >> 32) : (b >> 32);
+      return (hi << 32) | lo;
+   }
+};
+
+__device__ __forceinline__ uint32_t ann_half(unsigned long long v, int cls) { return (uint32_t)(cls ? v >> 32 : v & 0xffffffffull); }
+__device__ __forceinline__ unsigned long long ann_in_half(uint32_t v, int cls) { return cls ? (unsigned long long)v << 32 : (unsigned long long)v; }
+__device__ __forceinline__ int ann_lcp(const uint8_t *a, const uint8_t *b, int k) { int t = 0; while (t < k && a[t] == b[t]) t++; return t; }
+__device__ __forceinline__ const uint8_t *ann_letters(const AnnPlanArgs &P, int64_t g) { return P.text + sa_entry(P.ix.sa, P.ix.sar_bits, P.q_sa[g]); }
+// the budget of the left block of a searched query from its row of the phase tables (k_sc_prepare)
+__device__ __forceinline__ int ann_row_tl(int row, int tau) { return sc_tau_l((row >> 1) % (tau + 1), row & 1); }
+
+__global__ void __launch_bounds__(256) k_ann_plan_class(AnnPlanArgs P)
+{
+   const int64_t r = blockIdx.x * (int64_t)256 + threadIdx.x;
+   if (r >= P.nq) return;
+   P.s1[r] = ann_in_half((uint32_t)r + 1, P.q_fp[r] >= P.q_rp[r]);
+}
+
+__global__ void __launch_bounds__(256) k_ann_plan_trail(AnnPlanArgs P)
+{
+   const int64_t r = blockIdx.x * (int64_t)256 + threadIdx.x;
+   if (r >= P.nq) return;
+   const int cls = P.q_fp[r] >= P.q_rp[r];
+   const int row = P.read_row[r];
+   const uint32_t s = r > 0 ? ann_half(P.s1[r - 1], cls) : 0u;
+   const int64_t prev = s ? P.c0 + s - 1 : P.carry->prev[cls];
+   int trail = 0;
+   if (prev >= 0) {
+      trail = ann_lcp(ann_letters(P, prev), ann_letters(P, P.c0 + r), P.kmer);       // :786-789
+      if (trail < P.depth) trail = 0;                                                 // another job: fresh queries (:528-529)
+   }
+   const int pos_r = sc_pos_r(P.kmer, cls), leaf = (pos_r >> 1) + (pos_r & 1);
+   const bool wl = row != NO_ROW && trail < pos_r;                                    // src/blocksearch.c:73
+   const bool wll = wl && ann_row_tl(row, P.tau) == 1 && trail < leaf;                // :156
+   P.s2a[r] = wl ? ann_in_half((uint32_t)r + 1, cls) : 0ull;
+   P.s2b[r] = wll ? ann_in_half((uint32_t)r + 1, cls) : 0ull;
+}
+
+__global__ void __launch_bounds__(256) k_ann_plan_apply(AnnPlanArgs P)
+{
+   const int64_t r = blockIdx.x * (int64_t)256 + threadIdx.x;
+   if (r >= P.nq) return;
+   P.alias[r] = (uint32_t)r;
+   P.sc_flags[r] = 3;                                     // both leaves (those the row has), every step counts
+   const int row = P.read_row[r];
+   if (row == NO_ROW) return;
+   const int cls = P.q_fp[r] >= P.q_rp[r];
+   const int k = P.kmer, pos_r = sc_pos_r(k, cls), leaf = (pos_r >> 1) + (pos_r & 1);
+   const int64_t g = P.c0 + r;
+   const uint8_t *qi = ann_letters(P, g);
+   const uint32_t xl = ann_half(P.s2a[r], cls), xll = ann_half(P.s2b[r], cls);
+   int64_t ol = xl ? P.c0 + xl - 1 : P.carry->ol[cls];
+   int64_t oll = xll ? P.c0 + xll - 1 : P.carry->oll[cls];
+   const uint8_t *qo = nullptr, *qoo = nullptr;
+   if (ol >= 0) { qo = ann_letters(P, ol); if (ann_lcp(qo, qi, P.depth) < P.depth) ol = -1; }       // of another job
+   if (ol < 0) { P.read_row[r] = NO_ROW; return; }                                     // the tree's left stack is empty: no hits
+   if (oll >= 0) { qoo = ann_letters(P, oll); if (ann_lcp(qoo, qi, P.depth) < P.depth) oll = -1; }
+   const int64_t o_bound = xl ? P.sc_bound[xl - 1] : P.carry->ol_bound[cls];
+   const int o_tl = xl ? ann_row_tl(P.read_row[xl - 1], P.tau) : P.carry->ol_tl[cls];
+   const bool self = ol == g;
+   const uint32_t scp = 3u * (uint32_t)o_tl + 1u;          // the bounded extension's phase (build_sc_phase_table)
+   uint32_t leaves = 1, count_from = self ? 0u : scp;
+   bool split = false;
+   if (o_tl == 1) {
+      leaves = 3;
+      if (oll != ol) {                                     // the left block's search took its first leaf's hits from the tree
+         if (self) count_from = 1;
+         if (oll < 0) leaves = 2;                          // (none there)
+         else if (ann_lcp(qoo, qo, leaf) < leaf) split = true;                         // hits of other letters
+      }
+   }
+   int new_row = row;
+   if (!self) {
+      for (int t = 0; t < pos_r; t++) P.reads[r * (int64_t)P.stride + t] = qo[t];
+      new_row = P.n_nat + 2 * row + o_tl;
+      P.read_row[r] = (uint16_t)new_row;
+      P.sc_bound[r] = o_bound;
+   }
+   if (!split) { P.sc_flags[r] = (uint8_t)(leaves | (count_from << 2)); return; }
+   // two queries: the second leaf and what follows it as above; the first leaf, with the letters it was searched with, apart
+   P.sc_flags[r] = (uint8_t)(2u | ((self ? 0u : scp) << 2));
+   const int64_t q = P.nq + (int64_t)atomicAdd(P.n_extra, 1u);
+   uint8_t *dst = P.reads + q * (int64_t)P.stride;
+   for (int t = 0; t < P.stride; t++) dst[t] = t < leaf ? qoo[t] : (t < pos_r ? qo[t] : (t < k ? qi[t] : (uint8_t)0xff));
+   P.read_len[q] = (uint16_t)k;
+   P.read_row[q] = (uint16_t)new_row;
+   P.sc_bound[q] = o_bound;
+   P.score_add[q] = P.score_add[r];
+   P.sc_flags[q] = (uint8_t)(1u | ((self ? 1u : scp) << 2));
+   P.alias[q] = (uint32_t)r;
+}
+
+__global__ void k_ann_plan_carry(AnnPlanArgs P)
+{
+   if (P.nq < 1) return;
+   for (int cls = 0; cls < 2; cls++) {
+      const uint32_t s = ann_half(P.s1[P.nq - 1], cls), x = ann_half(P.s2a[P.nq - 1], cls), y = ann_half(P.s2b[P.nq - 1], cls);
+      if (s) P.carry->prev[cls] = P.c0 + s - 1;
+      if (x) {
+         P.carry->ol[cls] = P.c0 + x - 1;
+         P.carry->ol_bound[cls] = P.sc_bound[x - 1];
+         P.carry->ol_tl[cls] = ann_row_tl(P.read_row[x - 1], P.tau);
+      }
+      if (y) P.carry->oll[cls] = P.c0 + y - 1;
+   }
 }
 
 // hits_push as updates.  One thread per k-mer of the chunk: its hits are hit_*[lo .. hi) (sorted by k-mer).

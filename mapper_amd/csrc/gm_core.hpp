@@ -270,15 +270,20 @@ inline bool build_phase_table(int m, int tau, uint32_t *table, uint8_t *lo = nul
 // build_phase_table(pos_r, tau_l) gives them, phase 3*tau_l + 1 the bounded extension.  Returns 0 = search,
 // 1 = no search and no hits (:64-66; an empty left block: :73), -1 = where the reference returns -1 (and for an
 // empty right part, where it reads behind the query).
+// tau_l_forced >= 0: the left part is searched with that many mismatches instead (gpumap_ann_build with the
+// reference's reuse of the last k-mer's left block, whose search ran with the budget of the k-mer that made it).
 constexpr int SC_SEARCH = 0, SC_NO_HITS = 1, SC_ERROR = -1;
-inline int build_sc_phase_table(int slen, int tau_arg, int tau_eff, int last, uint32_t *table, uint8_t *lo, int *sc_phase, int *leaves)
+GM_HD int sc_pos_r(int slen, int last) { return slen / 2 + (last ? slen % 2 : 0); }                       // :69
+GM_HD int sc_tau_l(int tau_eff, int last) { return tau_eff / 2 - (last ? 0 : (1 - tau_eff % 2)); }       // :70
+inline int build_sc_phase_table(int slen, int tau_arg, int tau_eff, int last, uint32_t *table, uint8_t *lo, int *sc_phase, int *leaves,
+                                int tau_l_forced = -1)
 {
    *sc_phase = 0; *leaves = 0;
    if (slen < 1 || slen > MAX_READ) return SC_ERROR;
    if (tau_eff < 0 || (tau_eff == 0 && !last)) return SC_NO_HITS;                  // :64-66
    if (tau_arg == 0) return SC_ERROR;               // the caller's tree, alloc_stack_tree(0), has no left subtree (:74 -> :123)
-   const int pos_r = slen / 2 + (last ? slen % 2 : 0);                             // :69
-   const int tau_l = tau_eff / 2 - (last ? 0 : (1 - tau_eff % 2));                 // :70
+   const int pos_r = sc_pos_r(slen, last);                                         // :69
+   const int tau_l = tau_l_forced >= 0 ? tau_l_forced : sc_tau_l(tau_eff, last);   // :70
    if (pos_r > slen - 1) return SC_ERROR;
    if (pos_r == 0) return SC_NO_HITS;                                              // :73 with trail = 0
    PhaseBuilder b;

@@ -95,6 +95,8 @@ struct gpumap_ctx {
    bool pinned_results = false;       // "pinned_results": fetch into page-locked arenas of the batch
    bool compact_results = false;      // "compact_results": sorted 8-byte keys + CSR offsets instead of the structure of arrays
    int64_t hit_guess = 0;             // "hit_list_guess": first guess of the hit list's length in entries (0 = by the batch; tests)
+   bool ann_trail_reuse = true;       // "ann_trail_reuse": gpumap_ann_build reproduces the reference's reuse of the last k-mer's search (0: every k-mer afresh)
+   int ann_threads = 1;               // "ann_threads": the `threads` of the reference's ann_build whose job list is reproduced
    int64_t jump_budget = 0;           // "jump_bytes": most bytes the jump table may take (0 = a third of the free memory)
    std::vector<int64_t> seq_beg_host; // seq_beg[] (for gpumap_hits_expand)
    hipStream_t pipe_run = nullptr, pipe_copy = nullptr, pipe_up = nullptr;   // streams shared by the batches of pipelines (gm_ctx_pipe_streams)

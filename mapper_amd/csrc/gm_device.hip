@@ -45,6 +45,9 @@ struct gpumap_batch {
    DevBuf hkeys, hkeys_alt, hidx, hidx_alt, hit_read, hit_fp, hit_rp, hit_sz, hit_dp, hit_score, hit_align;
    DevBuf spill, counters, cub_tmp;
    DevBuf read_row, sc_bound, score_add, row_leaves, row_state, sc_qfp, sc_qrp;      // blocksc_trail (gm_batch_run with GM_RUN_SC)
+   DevBuf sc_flags, sc_alias;        // gpumap_ann_build with the reference's reuse of searches (sc_plan)
+   struct AnnPlanHost *sc_plan = nullptr;     // not owned; set by gpumap_ann_build around its runs
+   int extra_factor = 1;             // the per-query arrays hold room for extra_factor * n_reads queries (2 with sc_plan)
    DevBuf stage, stage2[2], iv_idx, iv_dense, blk_cnt, blk_off, blk_cnt2[2], blk_off2[2];      // what the blocks of k_verify / k_verify_group leave (keys, lists) and the scans of their counts
    DevBuf big_idx, big_dense, wide_idx, wide_dense, vsteps2[2];   // candidates of three and four suffixes (k_verify_group)
    const unsigned long long *sorted_keys = nullptr;     // the located hits' keys after the sort (in keys or keys_alt)
@@ -71,7 +74,7 @@ struct gpumap_batch {
       for (DevBuf *b : {&up_src, &up_off, &seen, &reads, &reads4, &read_len, &len_row, &row_len, &phases, &phase_rec, &phase_lo, &status, &hits, &hit_sizes, &hit_off, &vsteps, &longer, &keys, &keys_alt,
                         &read_cnt, &read_first, &loc_read, &loc_pos, &loc_fwd, &loc_seq, &loc_seqpos, &loc_strand,
                         &loc_score, &hkeys, &hkeys_alt, &hidx, &hidx_alt, &hit_read, &hit_fp, &hit_rp, &hit_sz,
-                        &hit_dp, &hit_score, &hit_align, &spill, &counters, &cub_tmp, &read_row, &sc_bound, &score_add, &row_leaves, &row_state, &sc_qfp, &sc_qrp,
+                        &hit_dp, &hit_score, &hit_align, &spill, &counters, &cub_tmp, &read_row, &sc_bound, &score_add, &row_leaves, &row_state, &sc_qfp, &sc_qrp, &sc_flags, &sc_alias,
                         &big_idx, &big_dense, &wide_idx, &wide_dense, &vsteps2[0], &vsteps2[1], &stage, &stage2[0], &stage2[1], &iv_idx, &iv_dense, &blk_cnt, &blk_off,
                         &blk_cnt2[0], &blk_cnt2[1], &blk_off2[0], &blk_off2[1]})
          b->release();
@@ -82,6 +85,15 @@ struct gpumap_batch {
       if (h_small) { (void)hipHostFree(h_small); h_small = nullptr; }
       if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
    }
+};
+// What gpumap_ann_build hands to gm_batch_run for the plan of gm_ann.hpp (the reference's reuse of searches).
+struct AnnPlanHost {
+   const int64_t *q_sa = nullptr;    // device: suffix-array entries of all k-mers searched
+   int64_t c0 = 0;                   // first k-mer of the chunk in the batch
+   int kmer = 0, depth = 1;
+   int64_t n_extra = 0;              // out: queries the plan added to the last chunk
+   DevBuf s1, s2a, s2b, carry, n_extra_dev, tmp;
+   void release() { for (DevBuf *b : {&s1, &s2a, &s2b, &carry, &n_extra_dev, &tmp}) b->release(); }
 };
 constexpr int CNT_WORDS = 16;       // [0] cursor [1] hits [2] n_ext [3] error [4..8] stats of k_search (SearchArgs::stats)
 constexpr int CNT_SUMS = 192;       // behind them: 64 partial sums of k_verify, 64 + 64 of the two launches of k_verify_group; then single words
@@ -413,6 +425,8 @@ extern "C" int gpumap_set_option(gpumap_ctx *ctx, const char *name, int64_t valu
    else if (!strcmp(name, "verify")) { GM_FAIL_IF(value != -1 && value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 16, "verify out of range (-1, 0, 1, 2, 4, 8, 16)."); ctx->verify = (int)value; }
    else if (!strcmp(name, "sort_all_bits")) ctx->sort_all_bits = value != 0;
    else if (!strcmp(name, "verify_tile")) { GM_FAIL_IF(value < 0 || value > VERIFY_TILE_MAX, "verify_tile out of range (0 = default, at most 1024)."); ctx->verify_tile = (int)value; }
+   else if (!strcmp(name, "ann_trail_reuse")) ctx->ann_trail_reuse = value != 0;
+   else if (!strcmp(name, "ann_threads")) { GM_FAIL_IF(value < 1, "argument 'threads' must be greater than 0."); ctx->ann_threads = (int)value; }
    else if (!strcmp(name, "jump_k")) { HIP_TRY(hipSetDevice(ctx->device)); GM_FAIL_IF(gm_ctx_build_jump(ctx, (int)value) != 0, "cannot build the jump table."); }
    else if (!strcmp(name, "spill_nodes")) { GM_FAIL_IF(value < 0 || value > (1 << 22), "spill_nodes out of range."); ctx->spill_cap = value ? ((value + SPILL_CHUNK - 1) / SPILL_CHUNK) * SPILL_CHUNK : 16384; }   // (batches size their spill regions at their next run)
    else GM_FAIL("unknown option.");
@@ -677,7 +691,7 @@ static int batch_encode(gpumap_ctx *ctx, gpumap_batch *b)
       }
       b->stride = (int)((maxlen + 127) & ~(int64_t)127);    // the rows as bit planes come in units of 128 symbols
       b->maxlen = (int)maxlen;
-      HIP_TRY(b->reads.ensure((size_t)n_reads * b->stride));
+      HIP_TRY(b->reads.ensure((size_t)n_reads * b->stride * (size_t)b->extra_factor));
       HIP_TRY(b->reads4.ensure((size_t)n_reads * (size_t)(12 * (b->stride / 32))));
       const int64_t groups = n_reads * (b->stride / 32);
       hipLaunchKernelGGL(k_encode, dim3((unsigned)std::min<int64_t>(cdiv(groups, 256), 1 << 22)), dim3(256), 0, st,
@@ -710,7 +724,7 @@ int gm_batch_fill(gpumap_ctx *ctx, gpumap_batch *b, const void *src, const int64
       b->n_reads = n_reads;
       b->ran = false; b->have_intervals = false; b->encoded = false;
       b->src_text = (src_flags & GM_SRC_TEXT) != 0;
-      HIP_TRY(b->read_len.ensure(2 * (size_t)std::max<int64_t>(1, n_reads)));
+      HIP_TRY(b->read_len.ensure(2 * (size_t)std::max<int64_t>(1, n_reads) * (size_t)b->extra_factor));
       HIP_TRY(b->status.ensure(8 * (size_t)std::max<int64_t>(1, n_reads)));
       int64_t total = 0;
       if (src_flags & GM_SRC_DEVICE) {
@@ -834,42 +848,51 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
       // ---- schedule: one phase-table row per read length present (src/blocksearch.c:138-170); for blocksc_trail
       // one per (length, tau - N count, strand class) (src/blocksearch.c:55-70)
       const bool sc = (result_flags & GM_RUN_SC) != 0;
+      int64_t RS = R;                 // queries the search runs (gpumap_ann_build's plan may add some behind the batch's)
       std::vector<uint16_t> len_row(MAX_READ + 1, NO_ROW);
       std::vector<uint32_t> phases, phase_rec;
       std::vector<uint8_t> phase_lo, row_leaves, row_state;
       std::vector<uint16_t> row_len;
       int rows = 0;
+      AnnPlanHost *plan = sc ? b->sc_plan : nullptr;
+      int n_nat = 0;                  // rows of the queries' own schedules (the plan's rows come behind them)
       if (sc) {
          int n_len = 0;
          for (int m = 1; m <= MAX_READ; m++) if (b->length_seen[m]) n_len++;
-         GM_FAIL_IF(n_len * (tau + 1) * 2 > 256, "too many distinct query lengths for one batch of blocksc_trail searches.");
+         GM_FAIL_IF(n_len * (tau + 1) * 2 * (plan ? 3 : 1) > 256, "too many distinct query lengths for one batch of blocksc_trail searches.");
+         auto add_row = [&](int m, int te, int last, int tl_forced) {
+            uint32_t tab[MAX_PHASES];
+            uint8_t lo_tab[MAX_PHASES];
+            memset(tab, 0, sizeof tab);
+            memset(lo_tab, 0, sizeof lo_tab);
+            int scp = 0, leaves = 0;
+            const int st = build_sc_phase_table(m, tau, te, last, tab, lo_tab, &scp, &leaves, tl_forced);
+            rows++;
+            row_len.push_back((uint16_t)m);
+            row_leaves.push_back((uint8_t)leaves);
+            row_state.push_back((uint8_t)(st == SC_SEARCH ? 0 : (st == SC_NO_HITS ? 1 : 2)));
+            phases.insert(phases.end(), tab, tab + MAX_PHASES);
+            phase_lo.insert(phase_lo.end(), lo_tab, lo_tab + MAX_PHASES);
+            for (int p = 0; p < MAX_PHASES; p++) {
+               uint32_t x = 0, y = 0;
+               if (st == SC_SEARCH && p <= scp) {
+                  phase_record(tab, p, x, y);
+                  if (phase_next(tab[p]) == scp) y |= 1u << 9;        // a hit of the left block enters the bounded extension
+               }
+               phase_rec.push_back(x); phase_rec.push_back(y);
+            }
+         };
          for (int m = 1; m <= MAX_READ; m++) {
             if (!b->length_seen[m]) continue;
             len_row[m] = (uint16_t)(rows / ((tau + 1) * 2));
             for (int te = 0; te <= tau; te++)
-               for (int last = 0; last < 2; last++) {
-                  uint32_t tab[MAX_PHASES];
-                  uint8_t lo_tab[MAX_PHASES];
-                  memset(tab, 0, sizeof tab);
-                  memset(lo_tab, 0, sizeof lo_tab);
-                  int scp = 0, leaves = 0;
-                  const int st = build_sc_phase_table(m, tau, te, last, tab, lo_tab, &scp, &leaves);
-                  rows++;
-                  row_len.push_back((uint16_t)m);
-                  row_leaves.push_back((uint8_t)leaves);
-                  row_state.push_back((uint8_t)(st == SC_SEARCH ? 0 : (st == SC_NO_HITS ? 1 : 2)));
-                  phases.insert(phases.end(), tab, tab + MAX_PHASES);
-                  phase_lo.insert(phase_lo.end(), lo_tab, lo_tab + MAX_PHASES);
-                  for (int p = 0; p < MAX_PHASES; p++) {
-                     uint32_t x = 0, y = 0;
-                     if (st == SC_SEARCH && p <= scp) {
-                        phase_record(tab, p, x, y);
-                        if (phase_next(tab[p]) == scp) y |= 1u << 9;        // a hit of the left block enters the bounded extension
-                     }
-                     phase_rec.push_back(x); phase_rec.push_back(y);
-                  }
-               }
+               for (int last = 0; last < 2; last++) add_row(m, te, last, -1);
          }
+         n_nat = rows;
+         // the plan's rows: row n_nat + 2 * r + tl = the schedule of row r with the left block searched with tl mismatches
+         if (plan)
+            for (int r = 0; r < n_nat; r++)
+               for (int tl = 0; tl < 2; tl++) add_row(row_len[(size_t)r], (r >> 1) % (tau + 1), r & 1, tl);
       }
       for (int m = 1; m <= MAX_READ && !sc; m++) {
          if (!b->length_seen[m]) continue;
@@ -915,9 +938,11 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
          GM_FAIL_IF(!h_leaves || !h_state, "row tables do not fit the staging block.");
          HIP_TRY(b->row_leaves.ensure(row_leaves.size()));
          HIP_TRY(b->row_state.ensure(row_state.size()));
-         HIP_TRY(b->read_row.ensure(2 * (size_t)std::max<int64_t>(R, 1)));
-         HIP_TRY(b->sc_bound.ensure(8 * (size_t)std::max<int64_t>(R, 1)));
-         HIP_TRY(b->score_add.ensure((size_t)std::max<int64_t>(R, 1)));
+         const size_t RX = (size_t)std::max<int64_t>(R, 1) * (size_t)b->extra_factor;
+         HIP_TRY(b->read_row.ensure(2 * RX));
+         HIP_TRY(b->sc_bound.ensure(8 * RX));
+         HIP_TRY(b->score_add.ensure(RX));
+         if (plan) { HIP_TRY(b->sc_flags.ensure(RX)); HIP_TRY(b->sc_alias.ensure(4 * RX)); }
          HIP_TRY(b->sc_qfp.ensure(8 * (size_t)std::max<int64_t>(R, 1)));
          HIP_TRY(b->sc_qrp.ensure(8 * (size_t)std::max<int64_t>(R, 1)));
          HIP_TRY(hipMemcpyAsync(b->row_leaves.p, h_leaves, row_leaves.size(), hipMemcpyHostToDevice, st));
@@ -930,6 +955,45 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
                             b->status.as<int64_t>(), b->sc_qfp.as<int64_t>(), b->sc_qrp.as<int64_t>(),
                             (const uint4 *)ctx->d_jump, ctx->jump_k, (const uint4 *)ctx->d_jump2, ctx->jump2_k);
          HIP_TRY(hipGetLastError());
+         if (plan) {
+            // the reference's reuse of the last k-mer's search (gm_ann.hpp): may patch queries and add some behind the R of the chunk
+            GM_FAIL_IF(b->extra_factor < 2 || tau > 5, "the batch is not set up for the plan.");
+            AnnPlanArgs P;
+            P.ix = ctx->ix; P.text = (const uint8_t *)ctx->d_text; P.q_sa = plan->q_sa; P.c0 = plan->c0; P.nq = R;
+            P.kmer = plan->kmer; P.tau = tau; P.depth = plan->depth; P.stride = b->stride; P.n_nat = n_nat;
+            P.q_fp = b->sc_qfp.as<const int64_t>(); P.q_rp = b->sc_qrp.as<const int64_t>();
+            P.reads = b->reads.as<uint8_t>(); P.read_len = b->read_len.as<uint16_t>(); P.read_row = b->read_row.as<uint16_t>();
+            P.sc_bound = b->sc_bound.as<int64_t>(); P.score_add = b->score_add.as<uint8_t>(); P.sc_flags = b->sc_flags.as<uint8_t>();
+            P.alias = b->sc_alias.as<uint32_t>();
+            for (DevBuf *x : {&plan->s1, &plan->s2a, &plan->s2b}) HIP_TRY(x->ensure(8 * (size_t)R));
+            HIP_TRY(plan->n_extra_dev.ensure(8));
+            P.s1 = plan->s1.as<unsigned long long>(); P.s2a = plan->s2a.as<unsigned long long>(); P.s2b = plan->s2b.as<unsigned long long>();
+            P.carry = plan->carry.as<AnnCarry>(); P.n_extra = plan->n_extra_dev.as<unsigned int>();
+            HIP_TRY(hipMemsetAsync(P.n_extra, 0, 8, st));
+            const dim3 pg((unsigned)cdiv(R, 256)), pb(256);
+            auto scan = [&](unsigned long long *v) -> hipError_t {
+               size_t bytes = 0;
+               hipError_t e = hipcub::DeviceScan::InclusiveScan(nullptr, bytes, v, v, MaxHalves(), (int)R, st);
+               if (e != hipSuccess) return e;
+               e = plan->tmp.ensure(bytes);
+               if (e != hipSuccess) return e;
+               return hipcub::DeviceScan::InclusiveScan(plan->tmp.p, bytes, v, v, MaxHalves(), (int)R, st);
+            };
+            hipLaunchKernelGGL(k_ann_plan_class, pg, pb, 0, st, P);
+            HIP_TRY(scan(P.s1));
+            hipLaunchKernelGGL(k_ann_plan_trail, pg, pb, 0, st, P);
+            HIP_TRY(scan(P.s2a));
+            HIP_TRY(scan(P.s2b));
+            hipLaunchKernelGGL(k_ann_plan_apply, pg, pb, 0, st, P);
+            hipLaunchKernelGGL(k_ann_plan_carry, dim3(1), dim3(1), 0, st, P);
+            HIP_TRY(hipGetLastError());
+            unsigned int *h_extra = reinterpret_cast<unsigned int *>(b->h_small + H_SMALL_BYTES - HOST_CNT_BYTES - 1024 + 768);
+            HIP_TRY(hipMemcpyAsync(h_extra, P.n_extra, 4, hipMemcpyDeviceToHost, st));
+            GM_SYNC(b, st);
+            plan->n_extra = (int64_t)*h_extra;
+            GM_FAIL_IF(plan->n_extra > R, "the plan added more queries than the batch has room for.");
+            RS = R + plan->n_extra;
+         }
       } else if (R > 0) {
          hipLaunchKernelGGL(k_status, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, st, b->read_len.as<const uint16_t>(),
                             b->len_row.as<const uint16_t>(), R, b->status.as<int64_t>());
@@ -982,7 +1046,7 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
          A.reads = b->reads.as<const uint8_t>(); A.read_len = b->read_len.as<const uint16_t>();
          A.len_row = b->len_row.as<const uint16_t>(); A.phases = b->phases.as<const uint32_t>();
          A.phase_rec = b->phase_rec.as<const uint2>(); A.n_rows = std::max(rows, 1);
-         A.n_reads = R; A.stride = b->stride; A.tau = tau;
+         A.n_reads = RS; A.stride = b->stride; A.tau = tau;
          A.cursor = cnt + 0; A.hits = b->hits.as<Node>(); A.hit_cap = hit_cap; A.hit_count = cnt + 1; A.n_ext = cnt + 2;
          A.spill = b->spill.as<Node>(); A.spill_cap = (uint32_t)ctx->spill_cap; A.error = (int *)(cnt + 3); A.stats = cnt + 4;
          A.jump = (const uint4 *)ctx->d_jump; A.jump_k = ctx->jump_k;
@@ -992,6 +1056,7 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
          A.read_row = sc ? b->read_row.as<const uint16_t>() : nullptr;
          A.sc_bound = sc ? b->sc_bound.as<const int64_t>() : nullptr;
          A.row_leaves = sc ? b->row_leaves.as<const uint8_t>() : nullptr;
+         A.sc_flags = plan ? b->sc_flags.as<const uint8_t>() : nullptr;
          {
             const int rpr = 64 / (tau + 1);
             int64_t k = R / std::max<int64_t>(1, n_waves * 8 * rpr);           // at least 8 reservations per wave: balance at the end
@@ -1255,12 +1320,12 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
          HIP_TRY(hipGetLastError());
       }
       if (want_intervals && H > 0) {
-         GM_FAIL_IF(R >= ((int64_t)1 << 24) - 1, "interval output supports fewer than 2^24 - 1 reads per batch.");
+         GM_FAIL_IF(RS >= ((int64_t)1 << 24) - 1, "interval output supports fewer than 2^24 - 1 reads per batch.");
          GM_FAIL_IF(H >= ((int64_t)1 << 31), "too many interval hits in one batch.");
          HIP_TRY(b->hkeys.ensure(8 * (size_t)H)); HIP_TRY(b->hkeys_alt.ensure(8 * (size_t)H));
          HIP_TRY(b->hidx.ensure(4 * (size_t)H)); HIP_TRY(b->hidx_alt.ensure(4 * (size_t)H));
          hipLaunchKernelGGL(k_hit_keys, dim3((unsigned)cdiv(H, 256)), dim3(256), 0, st, b->hits.as<const Node>(), H,
-                            b->hkeys.as<unsigned long long>(), b->hidx.as<unsigned int>());
+                            b->hkeys.as<unsigned long long>(), b->hidx.as<unsigned int>(), plan ? b->sc_alias.as<const uint32_t>() : (const uint32_t *)nullptr);
          hipcub::DoubleBuffer<unsigned long long> dk(b->hkeys.as<unsigned long long>(), b->hkeys_alt.as<unsigned long long>());
          hipcub::DoubleBuffer<unsigned int> dv(b->hidx.as<unsigned int>(), b->hidx_alt.as<unsigned int>());
          size_t tmp = 0;
@@ -1278,7 +1343,7 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
                             (const unsigned int *)dv.Current(), b->n_real, b->reads.as<const uint8_t>(), b->read_len.as<const uint16_t>(),
                             b->stride, b->hit_read.as<int64_t>(), b->hit_fp.as<int64_t>(), b->hit_rp.as<int64_t>(),
                             b->hit_sz.as<int64_t>(), b->hit_dp.as<int64_t>(), b->hit_score.as<int64_t>(), b->hit_align.as<uint64_t>(),
-                            sc ? b->score_add.as<const uint8_t>() : (const uint8_t *)nullptr);
+                            sc ? b->score_add.as<const uint8_t>() : (const uint8_t *)nullptr, plan ? b->sc_alias.as<const uint32_t>() : (const uint32_t *)nullptr);
          HIP_TRY(hipGetLastError());
       }
       b->have_intervals = want_intervals != 0;
@@ -1579,6 +1644,8 @@ extern "C" int gpumap_ann_build(gpumap_ctx *ctx, int kmer, int tau, uint8_t *tab
 {
    gpumap_batch *b = nullptr;
    DevBuf cls, rec, d_table, q_sa, n_sel, codes, offs, ukey, ukey2, uval, uval2, tmp;
+   AnnPlanHost plan;
+   hipEvent_t e0 = nullptr, e1 = nullptr;
    int rc = -1;
    GM_FAIL_IF(ctx == nullptr, "argument 'ctx' is NULL.");
    GM_FAIL_IF(table == nullptr, "argument 'table' is NULL.");
@@ -1607,8 +1674,11 @@ extern "C" int gpumap_ann_build(gpumap_ctx *ctx, int kmer, int tau, uint8_t *tab
       // per call of the device-wide primitives (they count their items in 32 bits)
       const int64_t piece = getenv("GPUMAP_ANN_PIECE") ? std::max<int64_t>(256, atoll(getenv("GPUMAP_ANN_PIECE"))) : ((int64_t)1 << 30);
       const int64_t launch_piece = piece;
-      int64_t n_ext = 0, n_hits = 0, n_updates = 0;
-      hipEvent_t e0, e1;
+      int64_t n_ext = 0, n_hits = 0, n_updates = 0, n_extra = 0;
+      // the reference cuts its jobs at prefixes of `depth` letters: the smallest depth with 5^depth >= 5 * threads (:116-121)
+      int depth = 1;
+      for (int64_t jobs = 5; jobs < 5 * (int64_t)ctx->ann_threads; jobs *= 5) depth++;
+      const bool reuse = ctx->ann_trail_reuse;
       HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
       HIP_TRY(hipEventRecord(e0, st));
       HIP_TRY(cls.ensure((size_t)n + 8));
@@ -1619,7 +1689,7 @@ extern "C" int gpumap_ann_build(gpumap_ctx *ctx, int kmer, int tau, uint8_t *tab
       HIP_TRY(hipMemsetAsync(d_table.p, 0, (size_t)half + 8, st));
       for (int64_t f = 0; f < n; f += launch_piece) {
          const int64_t l = std::min(n, f + launch_piece);
-         hipLaunchKernelGGL(k_ann_classify, dim3((unsigned)cdiv(l - f, 256)), dim3(256), 0, st, ctx->ix, text, kmer, tau, cls.as<uint8_t>(), f, l);
+         hipLaunchKernelGGL(k_ann_classify, dim3((unsigned)cdiv(l - f, 256)), dim3(256), 0, st, ctx->ix, text, kmer, tau, depth, cls.as<uint8_t>(), f, l);
       }
       HIP_TRY(hipGetLastError());
       // the k-mers to search, in suffix-array order
@@ -1641,9 +1711,20 @@ extern "C" int gpumap_ann_build(gpumap_ctx *ctx, int kmer, int tau, uint8_t *tab
       }
       b = gpumap_batch_new(ctx);
       GM_FAIL_IF(b == nullptr, "cannot create the batch.");
-      const int64_t chunk = getenv("GPUMAP_ANN_CHUNK") ? std::max<int64_t>(1, atoll(getenv("GPUMAP_ANN_CHUNK"))) : (int64_t)16000000;   // (interval output: < 2^24 queries per batch; 4 M: 5.6 s, 8 M: 5.1 s, 16 M: 4.9 s at 2.4 G symbols)
+      // (interval output: < 2^24 queries per batch; 4 M: 5.6 s, 8 M: 5.1 s, 16 M: 4.9 s at 2.4 G symbols.  With the reference's
+      // reuse of searches a k-mer can become two queries: half the chunk, so that any number of them fits)
+      const int64_t chunk = getenv("GPUMAP_ANN_CHUNK") ? std::max<int64_t>(1, atoll(getenv("GPUMAP_ANN_CHUNK"))) : (int64_t)(reuse ? 8000000 : 16000000);
+      if (reuse) {
+         AnnCarry fresh;
+         for (int c = 0; c < 2; c++) { fresh.prev[c] = fresh.ol[c] = fresh.oll[c] = -1; fresh.ol_bound[c] = 0; fresh.ol_tl[c] = 0; }
+         HIP_TRY(plan.carry.ensure(sizeof fresh));
+         HIP_TRY(hipMemcpy(plan.carry.p, &fresh, sizeof fresh, hipMemcpyHostToDevice));
+         plan.q_sa = q_sa.as<const int64_t>(); plan.kmer = kmer; plan.depth = depth;
+         b->sc_plan = &plan; b->extra_factor = 2;
+      }
       for (int64_t c0 = 0; c0 < n_q; c0 += chunk) {
          const int64_t nq = std::min(chunk, n_q - c0);
+         plan.c0 = c0;
          HIP_TRY(codes.ensure((size_t)nq * (size_t)kmer + 4));
          HIP_TRY(offs.ensure(8 * (size_t)(nq + 1)));
          hipLaunchKernelGGL(k_ann_gather, dim3((unsigned)cdiv(std::max<int64_t>(nq + 1, cdiv(nq * kmer, 4)), 256)), dim3(256), 0, st, ctx->ix, text, q_sa.as<const int64_t>() + c0, nq,
@@ -1653,7 +1734,8 @@ extern "C" int gpumap_ann_build(gpumap_ctx *ctx, int kmer, int tau, uint8_t *tab
          GM_FAIL_IF(gm_batch_fill(ctx, b, codes.p, offs.as<const int64_t>(), nq, GM_SRC_DEVICE, false) != 0, "cannot stage the k-mers.");
          GM_FAIL_IF(gm_batch_run(ctx, b, tau, 1, GM_RUN_SC | GM_RUN_NO_LOCATE) != 0, "the search of the k-mers failed.");
          const int64_t H = b->n_real, U = H + nq;
-         n_ext += b->n_ext; n_hits += H; n_updates += U;
+         GM_FAIL_IF(U >= ((int64_t)1 << 31), "too many hits in one chunk of k-mers (lower GPUMAP_ANN_CHUNK).");
+         n_ext += b->n_ext; n_hits += H; n_updates += U; n_extra += plan.n_extra;
          for (DevBuf *x : {&ukey, &ukey2, &uval, &uval2}) HIP_TRY(x->ensure(8 * (size_t)U));
          hipLaunchKernelGGL(k_ann_updates, dim3((unsigned)cdiv(nq, 256)), dim3(256), 0, st, nq, kmer, tau, b->sc_qfp.as<const int64_t>(),
                             b->sc_qrp.as<const int64_t>(), b->hit_read.as<const int64_t>(), b->hit_fp.as<const int64_t>(),
@@ -1697,15 +1779,19 @@ extern "C" int gpumap_ann_build(gpumap_ctx *ctx, int kmer, int tau, uint8_t *tab
       HIP_TRY(hipStreamSynchronize(st));
       float ms = 0;
       HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-      (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
       if (stats) {
          stats[0] = n_q; stats[1] = n_ext; stats[2] = n_hits; stats[3] = n_updates; stats[4] = (int64_t)(1000.0f * ms);
          stats[5] = ctx->jump2_k;                      // letters of the second jump table in place (0: none)
-         stats[6] = stats[7] = 0;
+         stats[6] = n_extra;                           // k-mers that the reuse of searches made two queries of
+         stats[7] = 0;
       }
    }
    rc = 0;
 failure_return:
+   if (e0) (void)hipEventDestroy(e0);
+   if (e1) (void)hipEventDestroy(e1);
+   if (b) b->sc_plan = nullptr;
+   plan.release();
    gpumap_batch_free(b);
    for (DevBuf *x : {&cls, &rec, &d_table, &q_sa, &n_sel, &codes, &offs, &ukey, &ukey2, &uval, &uval2, &tmp}) x->release();
    return rc;

@@ -360,6 +360,7 @@ struct SearchArgs {
    const uint16_t *read_row;
    const int64_t  *sc_bound;
    const uint8_t  *row_leaves;
+   const uint8_t  *sc_flags;    // nullptr, or per query: bits 0..1 the leaves it starts from, bits 2.. the first phase whose steps count (k_ann_plan_apply)
 };
 
 // blocksc_trail's set-up for every query of a batch (src/blocksearch.c:46-70 and what its callers compute before it,
@@ -1196,7 +1197,8 @@ __global__ void k_unpack_locs(IndexDev ix, const unsigned long long *keys, int64
 
 // Interval hits -> sortable keys (read, fp) and, after the sort, structure of arrays with the
 // mismatch bitmap rebuilt from the recorded positions and the query's N positions.
-__global__ void k_hit_keys(const Node *hits, int64_t n_hits, unsigned long long *keys, unsigned int *idx)
+// alias (or nullptr): the query a hit is reported under (gpumap_ann_build: a k-mer searched as two queries).
+__global__ void k_hit_keys(const Node *hits, int64_t n_hits, unsigned long long *keys, unsigned int *idx, const uint32_t *alias)
 {
    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
    if (i >= n_hits) return;
@@ -1205,21 +1207,21 @@ __global__ void k_hit_keys(const Node *hits, int64_t n_hits, unsigned long long 
    // reads < 2^24 - 1 per run, fp < 2^39 (n < 2^34); holes of the list (sz = 0) sort behind every hit, also where only the
    // bits [39, 63) are sorted (gpumap_ann_build; not [40, 64): hipcub's radix sort with begin_bit > 0 and end_bit = 64
    // returns unsorted keys for 10^4 .. 10^6 items on this ROCm, tools/sortpairs_check.hip)
-   keys[i] = h.sz > 0 ? (((unsigned long long)h.read << 39) | (unsigned long long)h.fp) : ~0ull;
+   keys[i] = h.sz > 0 ? (((unsigned long long)(alias ? alias[h.read] : h.read) << 39) | (unsigned long long)h.fp) : ~0ull;
    idx[i] = (unsigned int)i;
 }
 
 __global__ void k_unpack_hits(const Node *hits, const unsigned int *idx, int64_t n_hits, const uint8_t *reads,
                               const uint16_t *read_len, int stride, int64_t *hit_read, int64_t *hit_fp,
                               int64_t *hit_rp, int64_t *hit_sz, int64_t *hit_dp, int64_t *hit_score,
-                              uint64_t *hit_align_out, const uint8_t *score_add)
+                              uint64_t *hit_align_out, const uint8_t *score_add, const uint32_t *alias)
 {
    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
    if (i >= n_hits) return;
    NodeR h;
    unpack_node(hits[idx[i]], h);
    int m = read_len[h.read];
-   hit_read[i] = h.read; hit_fp[i] = h.fp; hit_rp[i] = h.rp; hit_sz[i] = h.sz;
+   hit_read[i] = alias ? alias[h.read] : h.read; hit_fp[i] = h.fp; hit_rp[i] = h.rp; hit_sz[i] = h.sz;
    hit_dp[i] = m;                       // one extension per letter (dp + 1 per bwt_query_all)
    hit_score[i] = h.score + (score_add ? score_add[h.read] : 0);
    uint64_t al[4];

@@ -235,10 +235,18 @@ __global__ void __launch_bounds__(WG_THREADS) k_search(SearchArgs A)
                      int row = SC ? A.read_row[rd] : (m <= MAX_READ ? A.len_row[m] : NO_ROW);
                      mk = row != NO_ROW;
                      if (SC && mk) mk = leaf < (int)A.row_leaves[row];          // tau_l + 1 leaves, by the query's class and N count
+                     // (gpumap_ann_build with the reference's reuse of searches: the leaves this query starts from, and the
+                     // first phase whose steps the reference executes for it; kept in byte 6 of the mismatch list, tau <= 5 there)
+                     uint32_t count_from = 0;
+                     if (SC && mk && A.sc_flags != nullptr) {
+                        const uint32_t f = A.sc_flags[rd];
+                        mk = (f >> leaf) & 1;
+                        count_from = f >> 2;
+                     }
                      if (mk) {
                         NodeR sd;
                         sd.fp = 0; sd.rp = 0; sd.sz = A.ix.n;        // bwt_new_query, src/index_bwt.c:48-52
-                        sd.read = rd; sd.score = 0; sd.mm = (uint64_t)row << 56;
+                        sd.read = rd; sd.score = 0; sd.mm = ((uint64_t)row << 56) | ((uint64_t)count_from << 48);
                         sd.sref = 0; sd.pos = sd.end = sd.tau = sd.diff = sd.phase = 0; sd.dash = sd.fw = false;
                         enter_phase(sd, leaf, A.phases[row * MAX_PHASES + leaf]);
                         // The first K steps of a leaf are an exact search from the root interval: one look-up in
@@ -261,7 +269,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_search(SearchArgs A)
                               sd.fp = (int64_t)e.x | ((int64_t)(e.w & 0xff) << 32);
                               sd.rp = (int64_t)e.y | ((int64_t)((e.w >> 8) & 0xff) << 32);
                               sd.sz = (int64_t)e.z | ((int64_t)((e.w >> 16) & 0xff) << 32);
-                              jump_steps += e.w >> 24;
+                              if (!SC || (uint32_t)leaf >= count_from) jump_steps += e.w >> 24;
                               sd.pos -= jk;
                               mk = sd.sz > 0;
                            }
@@ -310,7 +318,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_search(SearchArgs A)
       }
 #endif
       const int first = (int)(meta >> META_FIRST) & 7;
-      ext_count += (unsigned long long)__popcll(__ballot(have && first == 0));   // a continuation was counted at its first visit
+      ext_count += (unsigned long long)__popcll(__ballot(have && first == 0 && (!SC || (meta & 63u) >= (uint32_t)((mm >> 48) & 0xff))));   // a continuation was counted at its first visit
       n_iter++;
 
       // ------------------------------------------------------------ fetch: all loads first, then the hand-over
@@ -413,6 +421,10 @@ __global__ void __launch_bounds__(WG_THREADS) k_search(SearchArgs A)
                   // own left block are dropped (:76-85), the others start on the boundary (:91)
                   if (fp >= A.sc_bound[read]) have = false;
                   meta |= 1u << META_BOUND;
+                  // (a hit that already has more mismatches than this query allows, possible only where the left block was
+                  // searched with another query's budget: scsearch_fw extends it once and follows no child, :345-346;
+                  // without the dash flag no child is valid for it)
+                  if (s > ((rec.x >> META_TAU) & 7u)) meta &= ~(1u << META_DASH);
                }
             }
          }

@@ -1,8 +1,8 @@
 """GPU parity of gpumap_ann_build (ann_build, src/index_ann.c:56-257; SURVEY 8f rank 4: the reference's consumer of
 blocksc_trail) through the C-ABI: the annotation table, byte for byte, against the files the unmodified reference wrote
-(texts without N: there the reference's reuse of searches is exact) and against the oracle's restatement with every
-k-mer searched afresh (all texts; tests/test_oracle_ann.py pins the restatement to the reference); the number of
-k-mers searched and of extension steps; chunked runs; the reference's argument checks."""
+(every golden: texts with and without N, threads 1 and 2) and against the oracle's restatement in both of its modes
+(with the reference's reuse of the last k-mer's search, the default; every k-mer searched afresh); the number of
+k-mers searched and of extension steps; chunked runs (the reuse's state crossing chunks); the reference's argument checks."""
 import os
 
 import numpy as np
@@ -16,16 +16,25 @@ from tests.test_oracle_ann import CASES, WITH_N, load_golden
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name,k,tau,threads", [c for c in CASES if c[3] == 1])
+@pytest.mark.parametrize("name,k,tau,threads", CASES)
 def test_ann_table_matches_reference_and_oracle(workdir, name, k, tau, threads):
+    """Every golden, texts with N included, threads 1 and 2: the table is the file the unmodified reference wrote, byte for
+    byte (the default: with the reference's reuse of the last k-mer's search), and k-mers and extension steps are the
+    restatement's; with every k-mer searched afresh (ann_trail_reuse = 0) table and steps are the restatement's in that mode."""
     base = common.build_golden_index(workdir, name)
     ctx = ma.Context.from_files(base, 0)
-    got, st = ctx.ann_build(k, tau)
-    want, ost = po.Index(base).ann_build(k, tau, 1, trail_reuse=False)
+    orc = po.Index(base)
+    got, st = ctx.ann_build(k, tau, threads)
+    assert np.array_equal(got, load_golden(name, k, tau, threads))
+    want, ost = orc.ann_build(k, tau, threads, trail_reuse=True)
+    assert np.array_equal(got, want)
+    assert st["queries"] == ost["queries"] and st["n_ext"] == ost["n_ext"]
+    got, st = ctx.ann_build(k, tau, threads, trail_reuse=False)
+    want, ost = orc.ann_build(k, tau, threads, trail_reuse=False)
     assert np.array_equal(got, want)
     assert st["queries"] == ost["queries"] and st["n_ext"] == ost["n_ext"]
     if name not in WITH_N:
-        assert np.array_equal(got, load_golden(name, k, tau, 1))
+        assert np.array_equal(got, load_golden(name, k, tau, threads))
     ctx.close()
 
 
@@ -34,7 +43,7 @@ def test_ann_in_chunks_and_on_a_synthetic_text(workdir, monkeypatch):
     ctx = ma.Context.from_files(base, 0)
     orc = po.Index(base)
     for k, tau in ((22, 1), (18, 2)):
-        want, ost = orc.ann_build(k, tau, 1, trail_reuse=False)
+        want, ost = orc.ann_build(k, tau, 1, trail_reuse=True)
         got, st = ctx.ann_build(k, tau)
         assert np.array_equal(got, want) and st["n_ext"] == ost["n_ext"]
         monkeypatch.setenv("GPUMAP_ANN_CHUNK", "5000")
@@ -49,6 +58,32 @@ def test_ann_in_chunks_and_on_a_synthetic_text(workdir, monkeypatch):
     assert ma.lib().gpumap_ann_file_write(path.encode(), got.ctypes.data, len(got), 18, 2) == 0
     raw = np.fromfile(path, dtype=np.uint8)
     assert raw[:32].view(np.int64).tolist() == [0x0fcb0fcb00050001, 18, 2, len(got)] and np.array_equal(raw[32:], got)
+    ctx.close()
+
+
+def test_ann_reuse_next_to_n(workdir, monkeypatch):
+    """Texts in which every few k-mers hold an N: the reference's tree then keeps hits of other letters and other budgets
+    (src/blocksearch.c:41-43, :63-66, :73-86, :156-157) and its table depends on the order of the k-mers.  The table and
+    the steps are the restatement's with the reuse (pinned to the reference's files in tests/test_oracle_ann.py), whole and
+    in chunks of a few hundred k-mers (the state that crosses chunks), for one and for several threads' job lists."""
+    base = common.build_golden_index(workdir, "annN")         # tools/make_golden_ann.py: N in every few k-mers
+    ctx = ma.Context.from_files(base, 0)
+    orc = po.Index(base)
+    split = 0
+    for k, tau, threads in ((8, 3, 1), (9, 2, 1), (12, 3, 1), (13, 2, 3), (16, 1, 1), (7, 3, 6), (25, 2, 1)):
+        want, ost = orc.ann_build(k, tau, threads, trail_reuse=True)
+        fresh, _ = orc.ann_build(k, tau, threads, trail_reuse=False)
+        got, st = ctx.ann_build(k, tau, threads)
+        assert np.array_equal(got, want), (k, tau, threads, int(np.count_nonzero(got != want)), int(np.count_nonzero(fresh != want)))
+        assert st["queries"] == ost["queries"] and st["n_ext"] == ost["n_ext"]
+        monkeypatch.setenv("GPUMAP_ANN_CHUNK", "300")
+        got2, st2 = ctx.ann_build(k, tau, threads)
+        monkeypatch.delenv("GPUMAP_ANN_CHUNK")
+        assert np.array_equal(got2, want) and st2["n_ext"] == ost["n_ext"]
+        split += st["split"]
+        got3, st3 = ctx.ann_build(k, tau, threads, trail_reuse=False)
+        assert np.array_equal(got3, fresh)
+    assert split > 0                                       # some k-mers were searched as two queries
     ctx.close()
 
 

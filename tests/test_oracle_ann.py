@@ -5,9 +5,9 @@ reference wrote (tools/make_golden_ann.py -> oracle/_ref/ref_driver ann), thread
 Two forms of the restatement:
   trail_reuse = True    with the reference's reuse of the last k-mer's search, as it is: every table byte for byte,
                         also where that reuse is stale (next to k-mers with N)
-  trail_reuse = False   every k-mer searched afresh (blocksc_trail with trail = 0): what gpumap_ann_build computes.
-                        Equal to the reference on every text without N, and on the texts with N except for a few
-                        entries next to k-mers with N (counted here)
+  trail_reuse = False   every k-mer searched afresh (blocksc_trail with trail = 0): gpumap_ann_build with option
+                        ann_trail_reuse = 0.  Equal to the reference on every text without N; on the texts with N it
+                        differs next to k-mers with N (counted here; annN.fa is made of such places)
 and the known answers of test/test_index_ann.c:145-277 through gpumap_ann_query (host code of the library)."""
 import glob
 import os
@@ -26,7 +26,7 @@ CASES = []
 for f in FILES:
     m = re.match(r"(\w+)\.ann\.k(\d+)\.tau(\d+)\.t(\d+)\.bin", os.path.basename(f))
     CASES.append((m.group(1), int(m.group(2)), int(m.group(3)), int(m.group(4))))
-WITH_N = {"dense", "small"}
+WITH_N = {"dense", "small", "annN"}
 
 
 def load_golden(name, k, tau, threads):
@@ -52,7 +52,9 @@ def test_restatement_equals_the_reference_table(workdir, name, k, tau, threads):
     if name not in WITH_N:
         assert differ == 0
     else:
-        assert differ <= len(ref) // 10          # (dense, k 12, tau 2: 230 of 3002; small, k 24 / 16: none)
+        assert differ <= len(ref) // 4           # (dense, k 12, tau 2: 230 of 3002; small, k 24 / 16: none; annN, k 12, tau 3: 4415 of 20003)
+        if name == "annN" and k < 16:
+            assert differ > 100                  # these texts pin the stale reuse: a fresh search per k-mer gives another table
 
 
 def test_bad_arguments(workdir):
