@@ -145,8 +145,9 @@ int gpumap_query_all(gpumap_ctx *ctx, int end, int64_t n, const int64_t *fp, con
 ** ten words of -1. */
 int gpumap_prefix_all(gpumap_ctx *ctx, int64_t n, const int64_t *fp, const int64_t *sz, int64_t *out);
 /* gpumap_query_all without any allocation.  No counterpart in the reference: it is for callers that cannot
-** call hipMalloc (code under HIP graph capture, tight serving loops, harnesses that forbid allocation).
-** Same arguments and results as gpumap_query_all, at most GPUMAP_NOALLOC_MAX_QUERIES intervals per call
+** call hipMalloc (tight serving loops, harnesses that forbid allocation, a phase of a program in which the device
+** heap must not change).  The call copies from and to the caller's host arrays on the library's stream and waits for
+** it, so it cannot itself be recorded into a HIP graph.  Same arguments and results as gpumap_query_all, at most GPUMAP_NOALLOC_MAX_QUERIES intervals per call
 ** (-1 with a message beyond that).  The staging buffers are a static device array of 2.25 MiB that every GPU the
 ** library runs on holds until the process ends; every call on a GPU shares it, so calls that overlap
 ** on one GPU (also through different contexts) race: serialise them. */
@@ -299,10 +300,15 @@ void          gpumap_batch_free(gpumap_batch *batch);
 typedef struct gpumap_pipe gpumap_pipe;
 #define GPUMAP_PIPE_COMPACT 4
 gpumap_pipe *gpumap_pipe_create(gpumap_ctx *const *ctxs, int n_ctx, int depth, int tau, int flags);
-/* Hands a chunk to the pipe; blocks while all `depth` slots are taken (a slot is taken from submit to
-** release).  src / offsets must stay valid until the chunk's result has been returned.  `user` comes back
-** with the result. */
+/* Hands a chunk to the pipe.  A slot is taken from submit to release; while all `depth` slots are taken the call
+** waits for the caller's other thread (the one that calls gpumap_pipe_next / gpumap_pipe_release) to free one.  If no
+** other thread has ever taken a result (mapper() is single-threaded, src/mapper.c:23-40) nobody can free a slot: the
+** call then fails with -1 and a message (after 2 s of grace for a consumer thread that is only just starting) instead
+** of waiting for ever.  src / offsets must stay valid until the chunk's result has been returned.  `user` comes
+** back with the result.  Several threads may submit; the order of their chunks is the order the calls get the lock. */
 int          gpumap_pipe_submit(gpumap_pipe *pipe, const void *src, const int64_t *offsets, int64_t n_reads, void *user);
+/* The same without waiting: 1 = submitted, 0 = every slot is taken (take a result first), -1 = error. */
+int          gpumap_pipe_try_submit(gpumap_pipe *pipe, const void *src, const int64_t *offsets, int64_t n_reads, void *user);
 /* No more chunks will be submitted: gpumap_pipe_next returns 0 once everything has been returned. */
 void         gpumap_pipe_close(gpumap_pipe *pipe);
 /* Chunks submitted whose results have not been returned yet. */
@@ -342,13 +348,20 @@ void          gpumap_multi_destroy(gpumap_multi *multi);
 ** folded into one byte per position of the forward strand (hits_push :920-1071, neigh_push :664-729): bits 0-3 the
 ** class of the number of closest neighbours, bits 4-5 their distance - 1, bit 6 "mismatch positions known", bit 7
 ** "a closest neighbour of the k-mer that starts at an earlier marked position differs here".  `table` (host,
-** txt_len / 2 bytes) = ann->info of the reference with threads = 1, except next to k-mers with N, where the reference
-** reuses the search of another k-mer: every k-mer is searched afresh here, what blocksc_trail
-** computes with trail = 0.  Needs a context that holds the text; 17 bytes of device memory per symbol of the text
-** beside the index.  stats (may be NULL):
-** [0] k-mers searched, [1] extension steps, [2] hits, [3] updates of records, [4] microseconds on the device,
+** txt_len / 2 bytes) = ann->info of the reference, byte for byte, also next to k-mers with N, where the reference's
+** reuse of the last k-mer's search (`trail`, :552-570, src/blocksearch.c:41-43, :63-66, :73-86) extends hits that were
+** made for other letters or another budget.  Options of the context:
+**   "ann_threads" (default 1)      the `threads` argument of the reference whose job list is reproduced (it decides
+**                                  which suffixes are visited and where the reuse starts afresh, :116-132)
+**   "ann_trail_reuse" (default 1)  0 = every k-mer is searched afresh (blocksc_trail with trail = 0): the same table on
+**                                  texts without N, independent of the order of the k-mers everywhere
+** Needs a context that holds the text; 17 bytes of device memory per symbol of the text beside the index.
+** stats (may be NULL):
+** [0] k-mers searched, [1] extension steps (those the reference executes: none for blocks it takes from its tree),
+** [2] hits, [3] updates of records, [4] microseconds on the device,
 ** [5] letters of the second jump table the build put in place for the k-mers' left blocks (0: none; it stays with the
-** context and also serves reads whose leaf blocks the first table is too long for).
+** context and also serves reads whose leaf blocks the first table is too long for), [6] k-mers searched as two queries
+** (their first leaf block with the letters of an earlier k-mer).
 ** gpumap_ann_query = ann_query (:278-347) on such a table (align_pos: room for kmer entries, may be NULL);
 ** gpumap_ann_file_write = ann_file_write (:384-434): the file index_read picks up as <base>.ann.<kmer>.<tau>.
 ** ---------------------------------------------------------------------------------------- */

@@ -102,6 +102,7 @@ API = {
     "gpumap_hits_expand": (_I, [_P, C.POINTER(_Hits)]),
     "gpumap_batch_stats_ext": (_I, [_P, C.POINTER(_I64)]),
     "gpumap_pipe_create": (_P, [C.POINTER(_P), _I, _I, _I, _I]),
+    "gpumap_pipe_try_submit": (_I, [_P, _P, _P, _I64, _P]),
     "gpumap_pipe_submit": (_I, [_P, _P, _P, _I64, _P]),
     "gpumap_pipe_close": (None, [_P]),
     "gpumap_pipe_in_flight": (_I64, [_P]),
@@ -416,7 +417,21 @@ class Pipe:
             self._keep[self._seq] = (src, offsets)
             sp, op, n = _ptr(src), _ptr(offsets), len(offsets) - 1
         if lib().gpumap_pipe_submit(self._h, sp, op, n, C.c_void_p(self._seq)) != 0:
+            self._keep.pop(self._seq, None)
             raise GpumapError("gpumap_pipe_submit failed (see stderr)")
+        return self._seq
+
+    def try_submit(self, src, offsets):
+        """gpumap_pipe_try_submit with host numpy arrays: the chunk's tag, or None when every slot is taken."""
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        rc = lib().gpumap_pipe_try_submit(self._h, _ptr(src), _ptr(offsets), len(offsets) - 1, C.c_void_p(self._seq + 1))
+        if rc < 0:
+            raise GpumapError("gpumap_pipe_try_submit failed (see stderr)")
+        if rc == 0:
+            return None
+        self._seq += 1
+        self._keep[self._seq] = (src, offsets)
         return self._seq
 
     def next_raw(self):

@@ -236,7 +236,11 @@ extern "C" int gpumap_multi_map_batch(gpumap_multi *m, const uint8_t *codes, con
       for (int64_t g = 0; g < G; g++)
          th.emplace_back([&, g] {
             const int64_t lo = n_reads * g / G, hi = n_reads * (g + 1) / G;
-            rc[(size_t)g] = gpumap_map_batch(m->members[(size_t)g], codes, offsets + lo, hi - lo, tau, want_intervals, &parts[(size_t)g]);
+            gpumap_hits &part = parts[(size_t)g];
+            rc[(size_t)g] = gpumap_map_batch(m->members[(size_t)g], codes, offsets + lo, hi - lo, tau, want_intervals, &part);
+            // a member with option "compact_results" returns keys only: the concatenation below works on the full arrays
+            if (rc[(size_t)g] == 0 && part.loc_key != nullptr && part.loc_read == nullptr)
+               rc[(size_t)g] = gpumap_hits_expand(m->members[(size_t)g], &part);
          });
       for (auto &t : th) t.join();
       for (int x : rc) GM_FAIL_IF(x != 0, "a member failed.");

@@ -7,6 +7,8 @@
 // other two streams.  Chunks go round the slots, slots go round the contexts (GPUs), results come back in
 // submit order.
 // Host code only: the device work is behind gm_batch_fill / gm_batch_run / gm_batch_fetch (gm_device.hip).
+#include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
@@ -43,6 +45,10 @@ struct gpumap_pipe {
    // bursts of `depth`, the first after 58 ms instead of 18).  Uploads and result copies still overlap the runs.
    std::vector<uint64_t> ctx_submitted, ctx_turn;
    bool ordered = true;
+   // the last thread that took or released a result (gpumap_pipe_submit: can anyone but the submitting thread free a slot?)
+   bool consumer_seen = false;
+   std::thread::id consumer_tid;
+   int grace_ms = 2000;
    std::mutex m;
    std::condition_variable cv;
 };
@@ -115,6 +121,7 @@ extern "C" gpumap_pipe *gpumap_pipe_create(gpumap_ctx *const *ctxs, int n_ctx, i
    p->slots = std::vector<Slot>((size_t)depth * (size_t)n_ctx);
    p->ctx_submitted.assign((size_t)n_ctx, 0);
    p->ctx_turn.assign((size_t)n_ctx, 0);
+   if (getenv("GPUMAP_PIPE_GRACE_MS")) p->grace_ms = std::max(0, atoi(getenv("GPUMAP_PIPE_GRACE_MS")));
    p->ordered = !getenv("GPUMAP_PIPE_ORDERED") || atoi(getenv("GPUMAP_PIPE_ORDERED")) != 0;      // (0: tuning aid, the runs interleave)
    for (size_t i = 0; i < p->slots.size(); i++) {
       Slot &s = p->slots[i];
@@ -133,24 +140,53 @@ failure_return:
    return nullptr;
 }
 
-extern "C" int gpumap_pipe_submit(gpumap_pipe *p, const void *src, const int64_t *offsets, int64_t n_reads, void *user)
+static int pipe_submit(gpumap_pipe *p, const void *src, const int64_t *offsets, int64_t n_reads, void *user, bool may_block)
 {
+   bool full = false;
    GM_FAIL_IF(p == nullptr, "argument 'pipe' is NULL.");
    GM_FAIL_IF(offsets == nullptr || n_reads < 0, "invalid arguments.");
    {
       std::unique_lock<std::mutex> l(p->m);
       GM_FAIL_IF(p->closed, "the pipe is closed.");
+      // The slot of this chunk is the one the counter names once the wait is over (several threads may submit).
+      auto slot_free = [&] { return p->slots[p->submitted % p->slots.size()].state == SLOT_FREE; };
+      if (!slot_free()) {
+         if (!may_block) { full = true; goto failure_return; }      // gpumap_pipe_try_submit: not an error
+         // A slot is freed by gpumap_pipe_next (a failed chunk) or gpumap_pipe_release, which only the caller's threads
+         // call.  With every slot taken, a caller whose results are taken by this same thread (mapper() is single-threaded,
+         // src/mapper.c:23-40) would wait here for ever: unless another thread has been seen taking results (one that is
+         // just starting gets a moment), the call fails instead.
+         const std::thread::id me = std::this_thread::get_id();
+         auto other = [&] { return p->consumer_seen && p->consumer_tid != me; };
+         if (!other()) {
+            p->cv.wait_for(l, std::chrono::milliseconds(p->grace_ms), [&] { return slot_free() || other() || p->closed; });
+            GM_FAIL_IF(!slot_free() && !other(),
+                       "every slot of the pipe holds a chunk and no other thread takes results: call gpumap_pipe_next / gpumap_pipe_release before submitting more (or use gpumap_pipe_try_submit).");
+         }
+         p->cv.wait(l, [&] { return slot_free() || p->closed; });
+         GM_FAIL_IF(!slot_free(), "the pipe is closed.");
+      }
       Slot &s = p->slots[p->submitted % p->slots.size()];
-      p->cv.wait(l, [&] { return s.state == SLOT_FREE; });
       s.src = src; s.offsets = offsets; s.n_reads = n_reads; s.user = user;
       s.run_seq = p->ctx_submitted[(size_t)s.ctx_index]++;
       s.state = SLOT_QUEUED;
       p->submitted++;
    }
    p->cv.notify_all();
-   return 0;
+   return 1;
 failure_return:
-   return -1;
+   return full ? 0 : -1;
+}
+
+extern "C" int gpumap_pipe_submit(gpumap_pipe *p, const void *src, const int64_t *offsets, int64_t n_reads, void *user)
+{
+   return pipe_submit(p, src, offsets, n_reads, user, true) == 1 ? 0 : -1;
+}
+
+// 1: submitted; 0: every slot holds a chunk (take a result first); -1: error.  Never waits.
+extern "C" int gpumap_pipe_try_submit(gpumap_pipe *p, const void *src, const int64_t *offsets, int64_t n_reads, void *user)
+{
+   return pipe_submit(p, src, offsets, n_reads, user, false);
 }
 
 extern "C" int64_t gpumap_pipe_in_flight(gpumap_pipe *p)
@@ -172,6 +208,8 @@ extern "C" int gpumap_pipe_next(gpumap_pipe *p, gpumap_hits *out, void **user)
    GM_FAIL_IF(p == nullptr || out == nullptr, "NULL argument.");
    {
       std::unique_lock<std::mutex> l(p->m);
+      p->consumer_seen = true; p->consumer_tid = std::this_thread::get_id();
+      p->cv.notify_all();
       // a caller with a thread of its own for the results waits here for the submitting thread; a single-threaded
       // caller only asks when it has something in flight
       p->cv.wait(l, [&] { return p->returned < p->submitted || p->closed; });
@@ -200,6 +238,7 @@ extern "C" void gpumap_pipe_release(gpumap_pipe *p, gpumap_hits *hits)
    if (!p || !hits) return;
    {
       std::lock_guard<std::mutex> l(p->m);
+      p->consumer_seen = true; p->consumer_tid = std::this_thread::get_id();
       for (auto &s : p->slots)
          if (s.state == SLOT_RETURNED && s.hits.arena == hits->arena && s.hits.status == hits->status) { s.state = SLOT_FREE; break; }
    }

@@ -46,6 +46,22 @@ def test_members_on_one_device_give_the_output_of_one_gpu(setup, g):
     m.close()
 
 
+def test_a_member_with_compact_results_changes_nothing(setup):
+    """gpumap_multi_ctx hands the members out and options only change how results travel: a member set to
+    "compact_results" returns keys, which gpumap_multi_map_batch expands before it concatenates."""
+    base, hix, ctx, codes, offs, want = setup
+    m = ma.Multi.from_index(hix, 3, devices=[0, 0, 0])
+    mem = m.members()
+    mem[1].set_option("compact_results", 1)
+    mem[2].set_option("pinned_results", 1)
+    mem[2].set_option("compact_results", 1)
+    h = m.map_batch(codes, offs, 2)
+    assert np.array_equal(h.read_first_loc, want.read_first_loc)
+    for k in ("loc_read", "loc_pos", "loc_fwd", "loc_seq", "loc_seqpos", "loc_strand", "loc_score"):
+        assert np.array_equal(getattr(h, k), getattr(want, k)), k
+    m.close()
+
+
 def test_rccl_broadcast_path_on_one_rank(setup, monkeypatch):
     base, hix, ctx, codes, offs, want = setup
     monkeypatch.setenv("GPUMAP_MULTI_FORCE_RCCL", "1")

@@ -159,6 +159,31 @@ def test_pipe_returns_chunks_in_order(rep, depth, flags):
     p.close()
 
 
+def test_submit_from_one_thread_beyond_the_depth_is_an_error_not_a_hang(rep, capfd, monkeypatch):
+    """mapper() is single-threaded (src/mapper.c:23-40): a caller that submits depth + 1 chunks without taking a result
+    gets -1 and a message from gpumap_pipe_submit (nobody else could free a slot), and 0 from gpumap_pipe_try_submit;
+    after taking a result the pipe goes on, and every chunk comes back as submitted."""
+    base, seqs, ctx = rep
+    monkeypatch.setenv("GPUMAP_PIPE_GRACE_MS", "200")
+    codes, offs = _ragged_reads(seqs, 900, 21)
+    chunks = [(codes[offs[a]:offs[b]], offs[a:b + 1] - offs[a]) for a, b in ((0, 300), (300, 600), (600, 900))]
+    want = [ctx.map_batch(c, o, 2) for c, o in chunks]
+    p = ctx.pipe(depth=2, tau=2, flags=ma.PIPE_COMPACT)
+    p.submit(*chunks[0])
+    assert p.try_submit(*chunks[1]) is not None
+    assert p.try_submit(*chunks[2]) is None                   # every slot is taken: no wait, no error
+    with pytest.raises(ma.GpumapError):
+        p.submit(*chunks[2])
+    assert "every slot of the pipe holds a chunk" in capfd.readouterr().err
+    got = [p.next()]                                          # (takes and releases a result: a slot is free again)
+    p.submit(*chunks[2])
+    got += [p.next(), p.next()]
+    assert p.next() is None
+    for h, w in zip(got, want):
+        assert np.array_equal(h.located(), w.located()) and h.n_ext == w.n_ext
+    p.close()
+
+
 def test_pipe_with_two_threads_and_several_members_on_one_device(rep):
     """SURVEY 8e 'test without 8 GPUs': G members (contexts) sharing the device, chunks going round the members,
     a submitting and a consuming thread.  The concatenated output is that of one member."""

@@ -34,10 +34,13 @@ def test_query_all_noalloc_equals_query_all(workdir):
     n_txt = ma.HostIndex.read(base).txt_len
     fp, rp, sz = _intervals(ctx, n_txt, ma.NOALLOC_MAX_QUERIES, seed=5)
     # first call: the maximum size; second call: fewer intervals, other values, the other end
+    import torch
     for count, end, lo in ((ma.NOALLOC_MAX_QUERIES, ma.QUERY_PREFIX, 0), (777, ma.QUERY_SUFFIX, 1234), (1, ma.QUERY_PREFIX, 9)):
         a, b, c = fp[lo:lo + count], rp[lo:lo + count], sz[lo:lo + count]
+        want = ctx.query_all(end, a, b, c)              # (first: this one grows the context's staging with hipMalloc)
+        free_before = torch.cuda.mem_get_info(0)[0]
         got = ctx.query_all_noalloc(end, a, b, c)
-        want = ctx.query_all(end, a, b, c)
+        assert torch.cuda.mem_get_info(0)[0] == free_before      # the property itself: the device heap did not change
         assert got.shape == (count, 5, 3)
         assert np.array_equal(got, want)
     # invalid intervals give -1 rows exactly as gpumap_query_all does; an empty call succeeds

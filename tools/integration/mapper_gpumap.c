@@ -185,10 +185,13 @@ mapper_gpu_pipelined
       error_test_mem(c);
       c->rstack = rstack;
       error_test(flatten_chunk(rstack, &c->text, &c->off) == -1);
-      /* single-threaded caller: take a result when every slot is taken, then submit */
-      if (gpumap_pipe_in_flight(pipe) == DEPTH)
+      /* single-threaded caller: never waits inside the pipe; takes a result whenever every slot is taken */
+      for (;;) {
+         int rc = gpumap_pipe_try_submit(pipe, c->text, c->off, gstack_num_elm(rstack), c);
+         error_test(rc == -1);
+         if (rc == 1) break;
          error_test(print_chunk(pipe, index) == -1);
-      error_test(gpumap_pipe_submit(pipe, c->text, c->off, gstack_num_elm(rstack), c) == -1);
+      }
    }
    gpumap_pipe_close(pipe);
    for (;;) {
