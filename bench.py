@@ -81,6 +81,9 @@ def main():
     ap.add_argument("--device-build", action="store_true", help="generate and index in HBM also for the small workloads")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N > 1 "
                     "on a box with fewer GPUs than ranks: ranks then share devices)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the N > 1 code path with any N, also 1: process group (RCCL), broadcast of the index arrays, a replica "
+                         "created from the broadcast buffers (gpumap_create_from_device) that serves the timed region, replica check")
     args = ap.parse_args()
 
     import torch
@@ -97,8 +100,10 @@ def main():
     if args.backend != "nccl":
         local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
-    if world > 1:
+    dist_on = world > 1 or args.force_dist
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
@@ -116,7 +121,7 @@ def main():
     tmp = tempfile.mkdtemp(prefix="gpumap_bench_")
     base = os.path.join(tmp, args.workload)
     keep = []
-    t_index = t_upload = t_bcast = 0.0
+    t_index = t_upload = t_bcast = t_replica = 0.0
     want_cpu = not args.no_cpu_baseline and world == 1
     read_seed = w["seed"] * 1000 + 17 + rank
     if on_device:
@@ -128,7 +133,7 @@ def main():
         note("sequences generated")
         if rank == 0:
             t0 = time.time()
-            ctx = ma.Context.build_device(lens, local, keep_reference=want_cpu, device_ptr=g.data_ptr())
+            ctx = ma.Context.build_device(lens, local, keep_reference=want_cpu or dist_on, device_ptr=g.data_ptr())
             t_index = time.time() - t0
         seqs = None
     else:
@@ -141,7 +146,8 @@ def main():
             t0 = time.time()
             ctx = ma.Context.from_index(hix, local)
             t_upload = time.time() - t0
-    if world > 1:
+    root_ctx = ctx if rank == 0 else None
+    if dist_on:
         # one-off replication of the device-resident index: RCCL broadcast over xGMI
         t0 = time.time()
         if rank == 0:
@@ -167,12 +173,18 @@ def main():
             bufs.append(t)
             note("broadcast of buffer %d done (%d bytes)" % (i, nbytes))
         torch.cuda.synchronize()
-        if rank != 0:
+        t_bcast = time.time() - t0
+        if rank != 0 or args.force_dist:
+            # (--force-dist on rank 0: the replica takes the root's place; the root keeps the arrays alive and gives
+            # up its own jump table, so that two of them do not sit in one GPU's memory)
+            t0 = time.time()
+            if rank == 0:
+                root_ctx.set_option("jump_k", 0)
             d = ma.DevIndex(bufs[0].data_ptr(), meta[1], bufs[1].data_ptr(), meta[2], bufs[2].data_ptr(), meta[3],
                             bufs[3].data_ptr() if bufs[3] is not None else None, meta[4])
             ctx = ma.Context.from_device(d, meta[0], local, keep=bufs)
+            t_replica = time.time() - t0
         keep = bufs
-        t_bcast = time.time() - t0
     if args.waves_per_cu:
         ctx.set_option("waves_per_cu", args.waves_per_cu)
     if args.verify >= 0:
@@ -208,7 +220,7 @@ def main():
     offs = np.arange(w["reads"] + 1, dtype=np.int64) * w["m"]
     # N > 1: one small sample that every rank maps against its own replica (the same reads on every rank)
     sample = synth_device.make_reads(g, lens, min(20000, w["reads"]), w["m"], w["tau"], seed=w["seed"] * 1000 + 5).cpu().numpy() \
-        if world > 1 else None
+        if dist_on else None
     del g
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
@@ -217,7 +229,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -258,7 +270,7 @@ def main():
     located_total = run_steps(args.steps, first=args.warmup)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -286,7 +298,7 @@ def main():
     ctx.set_option("compact_results", 0)
     # replicas: every rank maps the same small sample; the checksums of the sorted keys must agree
     replica = None
-    if world > 1:
+    if dist_on:
         ns = len(sample)
         h = ctx.map_batch(sample.reshape(-1), offs[:ns + 1], w["tau"])
         mine = np.array([int(h.n_locs), int(np.bitwise_xor.reduce(h.located().reshape(-1) * np.int64(0x9E3779B97F4A7C15 >> 1))) if h.n_locs else 0],
@@ -295,6 +307,15 @@ def main():
         dist.all_gather(allv, torch.from_numpy(mine).cuda())
         allv = [tuple(v.cpu().tolist()) for v in allv]
         replica = {"sample_reads": ns, "located": int(mine[0]), "identical_across_ranks": len(set(allv)) == 1}
+        if rank == 0 and not args.no_cpu_baseline:
+            # and against the oracle (the checker: test infrastructure), on the root's reference-layout arrays
+            orc = oracle_of(root_ctx if on_device else None, base)
+            no = min(ns, 4000)
+            d = orc.map_batch(sample[:no].reshape(-1), offs[:no + 1], w["tau"], threads=cpu_share())
+            ho = ctx.map_batch(sample[:no].reshape(-1), offs[:no + 1], w["tau"])
+            replica["oracle_sample_reads"] = no
+            replica["identical_to_oracle"] = bool(np.array_equal(ho.status, d.status) and np.array_equal(ho.located(), d.located())
+                                                  and ho.n_ext == d.n_ext)
 
     if rank == 0:
         total_reads = n_reads * world * args.steps
@@ -373,21 +394,23 @@ def main():
                           "steps_on_occ_table": occ_steps,
                           "lane_fill": (occ_steps / (64.0 * c["loop_passes"])) if c["loop_passes"] else None},
             "setup_s": {"index_build": t_index, "index_built_on": "device" if on_device else "host", "upload_repack": t_upload, "rccl_broadcast": t_bcast,
-                        "all": t_setup},
+                        "replica_from_device": t_replica, "all": t_setup},
         }
         if replica:
             out["replica_check"] = replica
         if world == 1 and not args.no_pcie:
             out["pcie_inclusive"] = pcie_inclusive(ma, ctx, codes, offs, w, args.depth)
         if want_cpu:
-            out["cpu_baseline"] = cpu_baseline(ctx if on_device else None, base, codes, offs, w, args.cpu_seconds, gpu_ctx=ctx)
+            out["cpu_baseline"] = cpu_baseline(root_ctx if on_device else None, base, codes, offs, w, args.cpu_seconds, gpu_ctx=ctx)
         print(json.dumps(out), flush=True)
     batch.close()
     pipe.close()
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+    if root_ctx is not None and root_ctx is not ctx:
+        root_ctx.close()
     del keep
 
 
@@ -486,24 +509,34 @@ def pmc_traffic(workload):
     return None, None, None
 
 
+def oracle_of(ctx, base):
+    """The oracle (test infrastructure; here the checker and the CPU baseline) on the index files the host builder wrote, or
+    on the reference-layout arrays of a device build copied back."""
+    from oracle import pyoracle as po
+    if ctx is None:
+        return po.Index(base)
+    ref = ctx.reference_arrays(want_text=False)
+    return po.Index.from_arrays(ref["occ"], ref["c"], ref["sa"], ref["sar_bits"], ref["txt_len"], ref["wil_cnt"])
+
+
+def cpu_share():
+    try:
+        share = len(os.sched_getaffinity(0))
+    except Exception:
+        share = os.cpu_count() or 1
+    if os.environ.get("OMP_NUM_THREADS", "").isdigit():
+        share = min(share, int(os.environ["OMP_NUM_THREADS"]))          # the box's CPU share per GPU job
+    return share
+
+
 def cpu_baseline(ctx, base, codes, offs, w, seconds, gpu_ctx=None):
     """The oracle's C restatement (kind "port") on the host cores, on a bounded sample of the same
     reads against the same index (the files the host builder wrote, or the reference-layout arrays of
     a device build copied back).  Test infrastructure used as the baseline only.  Three thread counts: 1, the CPUs
     this job may run on (its affinity mask / the box's share), and nproc (every CPU the machine shows)."""
-    from oracle import pyoracle as po
-    if ctx is None:
-        orc = po.Index(base)
-    else:
-        ref = ctx.reference_arrays(want_text=False)
-        orc = po.Index.from_arrays(ref["occ"], ref["c"], ref["sa"], ref["sar_bits"], ref["txt_len"], ref["wil_cnt"])
+    orc = oracle_of(ctx, base)
     nproc = os.cpu_count() or 1
-    try:
-        share = len(os.sched_getaffinity(0))
-    except Exception:
-        share = nproc
-    if os.environ.get("OMP_NUM_THREADS", "").isdigit():
-        share = min(share, int(os.environ["OMP_NUM_THREADS"]))          # the box's CPU share per GPU job
+    share = cpu_share()
     runs = {}
     best_t, best_d, best_n = None, None, 0
     for T in sorted(set([1, share, min(nproc, 512)])):

@@ -336,6 +336,9 @@ gpumap_multi *gpumap_create_multi(const gpumap_index_view *view, int n_members, 
 gpumap_multi *gpumap_multi_from_ctx(gpumap_ctx *root, int root_device, int n_members, const int *devices);
 int           gpumap_multi_size(const gpumap_multi *multi);
 int           gpumap_multi_used_rccl(const gpumap_multi *multi);   /* 1: the arrays went through ncclBroadcast */
+/* Milliseconds of the set-up: i = -1 the broadcast of the arrays; i >= 1 what member i took to adopt them and derive
+** its own tables (jump table, bit planes), the members working side by side. */
+double        gpumap_multi_setup_ms(const gpumap_multi *multi, int i);
 gpumap_ctx   *gpumap_multi_ctx(const gpumap_multi *multi, int i);
 gpumap_ctx *const *gpumap_multi_ctxs(const gpumap_multi *multi);
 int           gpumap_multi_map_batch(gpumap_multi *multi, const uint8_t *codes, const int64_t *offsets, int64_t n_reads,

@@ -103,6 +103,7 @@ API = {
     "gpumap_batch_stats_ext": (_I, [_P, C.POINTER(_I64)]),
     "gpumap_pipe_create": (_P, [C.POINTER(_P), _I, _I, _I, _I]),
     "gpumap_pipe_try_submit": (_I, [_P, _P, _P, _I64, _P]),
+    "gpumap_multi_setup_ms": (C.c_double, [_P, _I]),
     "gpumap_pipe_submit": (_I, [_P, _P, _P, _I64, _P]),
     "gpumap_pipe_close": (None, [_P]),
     "gpumap_pipe_in_flight": (_I64, [_P]),
@@ -344,6 +345,10 @@ class Multi:
     @property
     def used_rccl(self):
         return bool(lib().gpumap_multi_used_rccl(self._h))
+
+    def setup_ms(self):
+        """{"broadcast": ms, "members": [ms per member; member 0 is the root]}"""
+        return {"broadcast": lib().gpumap_multi_setup_ms(self._h, -1), "members": [lib().gpumap_multi_setup_ms(self._h, i) for i in range(len(self))]}
 
     def members(self):
         """The members as Context objects that do not own their handles."""

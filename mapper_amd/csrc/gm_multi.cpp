@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <thread>
@@ -64,6 +65,8 @@ struct gpumap_multi {
    std::vector<bool> owned;               // members this object created (the root may be the caller's)
    std::vector<DeviceCopy> copies;
    bool used_rccl = false;
+   double bcast_ms = 0;                   // set-up times: the broadcast of the arrays, and per member its own tables (jump table, bit planes)
+   std::vector<double> member_ms;
 };
 
 extern "C" void gpumap_multi_destroy(gpumap_multi *m)
@@ -157,18 +160,38 @@ extern "C" gpumap_multi *gpumap_multi_from_ctx(gpumap_ctx *root, int root_device
             if (bytes[a] > 0) HIP_TRY(hipMalloc(&m->copies.back().buf[a], (size_t)bytes[a]));
       }
       if (!m->copies.empty() || force) {
+         const auto t0 = std::chrono::steady_clock::now();
          GM_FAIL_IF(broadcast_arrays(dev, root_device, m->copies) != 0, "cannot broadcast the index.");
+         m->bcast_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
          m->used_rccl = true;
       }
+      // every member derives its own jump table and bit planes on its GPU (1.5 s + at GRCh38 size): all at once, a thread
+      // per member (members that share a GPU queue up on it)
+      std::vector<gpumap_ctx *> made((size_t)n_members, nullptr);
+      std::vector<std::thread> th;
+      m->member_ms.assign((size_t)n_members, 0.0);
+      for (int i = 1; i < n_members; i++)
+         th.emplace_back([&, i] {
+            const int d = devices ? devices[i] : i;
+            const auto t0 = std::chrono::steady_clock::now();
+            gpumap_devindex mine = dev;
+            for (auto &c : m->copies)
+               if (c.device == d) { mine.occ_blocks = c.buf[0]; mine.sa_words = c.buf[1]; mine.tables = c.buf[2]; mine.text = c.buf[3]; }
+            made[(size_t)i] = gpumap_create_from_device(&mine, header.data(), d);
+            m->member_ms[(size_t)i] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+         });
+      for (auto &t : th) t.join();
+      bool all = true;
       for (int i = 1; i < n_members; i++) {
-         const int d = devices ? devices[i] : i;
-         gpumap_devindex mine = dev;
-         for (auto &c : m->copies)
-            if (c.device == d) { mine.occ_blocks = c.buf[0]; mine.sa_words = c.buf[1]; mine.tables = c.buf[2]; mine.text = c.buf[3]; }
-         gpumap_ctx *ctx = gpumap_create_from_device(&mine, header.data(), d);
-         GM_FAIL_IF(ctx == nullptr, "cannot create a member.");
-         m->members.push_back(ctx);
+         if (made[(size_t)i] == nullptr) { all = false; continue; }
+         m->members.push_back(made[(size_t)i]);
          m->owned.push_back(true);
+      }
+      GM_FAIL_IF(!all, "cannot create a member.");
+      if (getenv("GPUMAP_VERBOSE")) {
+         fprintf(stderr, "gpumap_multi: broadcast %.0f ms; members:", m->bcast_ms);
+         for (int i = 1; i < n_members; i++) fprintf(stderr, " %.0f", m->member_ms[(size_t)i]);
+         fprintf(stderr, " ms\n");
       }
    }
    return m;
@@ -195,6 +218,13 @@ failure_return:
 
 extern "C" int gpumap_multi_size(const gpumap_multi *m) { return m ? (int)m->members.size() : 0; }
 extern "C" int gpumap_multi_used_rccl(const gpumap_multi *m) { return m && m->used_rccl ? 1 : 0; }
+// Milliseconds of the set-up: i = -1 the broadcast of the arrays, i >= 1 what member i took to derive its own tables.
+extern "C" double gpumap_multi_setup_ms(const gpumap_multi *m, int i)
+{
+   if (!m) return 0.0;
+   if (i < 0) return m->bcast_ms;
+   return i < (int)m->member_ms.size() ? m->member_ms[(size_t)i] : 0.0;
+}
 extern "C" gpumap_ctx *gpumap_multi_ctx(const gpumap_multi *m, int i)
 {
    return (m && i >= 0 && i < (int)m->members.size()) ? m->members[(size_t)i] : nullptr;

@@ -90,3 +90,22 @@ def test_mapper_over_members_writes_what_one_gpu_writes(setup, workdir, monkeypa
     assert open(out, "rb").read() == open(one, "rb").read()
     assert os.path.getsize(one) > 100000
     m.close()
+
+
+def test_bench_runs_its_distributed_path_on_one_gpu():
+    """bench.py --force-dist: what the driver's N > 1 runs execute (process group on RCCL, broadcast of the index arrays
+    through __cuda_array_interface__ views in 1-GiB pieces, gpumap_create_from_device on the received buffers, barrier and
+    max over ranks, replica check across ranks and against the oracle), with a world of one rank."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "ecoli", "--reads", "20000", "--steps", "3", "--warmup", "1",
+                        "--force-dist", "--no-pcie", "--cpu-seconds", "1"], capture_output=True, text=True, timeout=280, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0
+    assert line["replica_check"]["identical_across_ranks"] and line["replica_check"]["identical_to_oracle"]
+    assert line["setup_s"]["rccl_broadcast"] > 0 and line["setup_s"]["replica_from_device"] > 0
+    assert line["cpu_baseline"]["parity_on_sample"]["identical"]
