@@ -168,6 +168,10 @@ int gpumap_encode(gpumap_ctx *ctx, const char *text, const int64_t *offsets, int
 ** the reference never leaves the host. */
 void *gpumap_host_alloc(size_t bytes);
 void  gpumap_host_free(void *p);
+/* The library keeps the page-locked blocks of finished pipelines and mapper() calls for the next ones (allocating
+** them costs about as much as mapping the chunk they hold; at most GPUMAP_PINNED_POOL_BYTES, default 8 GiB): this call
+** frees the ones not in use. */
+void  gpumap_host_trim(void);
 
 /* ------------------------------------------------------------------------------------------
 ** Read mapping: blocksearch_trail_rec(q, 0, m-1, tau+1, 0, bwt, tree) for every read, then
@@ -214,6 +218,11 @@ typedef struct {
    uint64_t *loc_key;         /* [n_locs] */
    int32_t   key_pos_bits;    /* = sar_bits of the index */
    int32_t   expanded;        /* gpumap_hits_expand has filled loc_read .. loc_score (malloc'ed) */
+   /* Hit lines (GPUMAP_PIPE_LINES): the located hits as the text mapper() prints, one line per hit in the order of
+   ** the loc_* arrays, "tag \t name:pos:strand \t score \n" (txt_pos_to_str, src/index_txt.c:480-511); every other
+   ** array is NULL then (n_reads, n_locs, n_ext are set).  NULL otherwise. */
+   char     *line_text;       /* [line_bytes], not NUL-terminated */
+   int64_t   line_bytes;
 } gpumap_hits;
 #define GPUMAP_KEY_SCORE(k)       ((int)((k) & 15))
 #define GPUMAP_KEY_POS(k, bits)   ((int64_t)(((k) >> 4) & ((1ull << (bits)) - 1ull)))
@@ -262,6 +271,15 @@ gpumap_batch *gpumap_batch_new(gpumap_ctx *ctx);
 ** copied to the device by the time the batch has been run. */
 #define GPUMAP_SRC_TEXT   1
 #define GPUMAP_SRC_DEVICE 2
+/* GPUMAP_SRC_FILE (gpumap_pipe only) = `src` holds a block of a FASTQ / FASTA / raw read file (host memory) that starts
+** at the first line of a record, and `offsets` points to five int64 that describe it: [0] its bytes (< 2 GiB), [1] lines
+** per record (4 FASTQ, 2 FASTA, 1 raw: io_stream_set_parser, src/io.c:232-266), [2] the lines it holds (a last line
+** without newline counts), [3] unused, [4] the line number of its first line in the file (raw files: a read's tag is
+** its line number, src/io.c:171-174); n_reads = the records to map (whole records only: [2] / [1] at most).  The block
+** is parsed on the device by the rules of seqread_parse_fastq / _fasta (src/seqread.c:119-164): sequence = line 1 of a
+** record (line 0 of a raw file), tag = line 0 without its first character, a line ends at its newline or at a NUL, a
+** FASTQ quality line of another length than the sequence fails the chunk. */
+#define GPUMAP_SRC_FILE   8
 int           gpumap_batch_stage(gpumap_ctx *ctx, gpumap_batch *batch, const void *src, const int64_t *offsets,
                                  int64_t n_reads, int flags);
 /* The arrays loc_read .. loc_score of a compact result, derived on the host from loc_key by the rule of
@@ -294,11 +312,15 @@ void          gpumap_batch_free(gpumap_batch *batch);
 ** the device, the search of chunk i and the copy of the results of chunk i-1 to the host overlap.  Chunks
 ** come back in the order they went in.  With several contexts (replicas of the index on several GPUs,
 ** gpumap_multi) the chunks go round the GPUs: reads stay in input order.
-**   flags: GPUMAP_SRC_TEXT, GPUMAP_SRC_DEVICE (as gpumap_batch_stage), GPUMAP_PIPE_COMPACT (compact results).
+**   flags: GPUMAP_SRC_TEXT, GPUMAP_SRC_DEVICE (as gpumap_batch_stage), GPUMAP_SRC_FILE (blocks of the read file, parsed
+**   on the device), GPUMAP_PIPE_COMPACT (compact results), GPUMAP_PIPE_LINES (hit lines made on the device).
 ** Results lie in page-locked arenas of the pipe and stay valid until gpumap_pipe_release.
 ** ---------------------------------------------------------------------------------------- */
 typedef struct gpumap_pipe gpumap_pipe;
 #define GPUMAP_PIPE_COMPACT 4
+/* Results as hit lines (gpumap_hits.line_text), formatted on the device; needs GPUMAP_SRC_FILE (the tags) and
+** gpumap_set_seq_names on every context of the pipe. */
+#define GPUMAP_PIPE_LINES   16
 gpumap_pipe *gpumap_pipe_create(gpumap_ctx *const *ctxs, int n_ctx, int depth, int tau, int flags);
 /* Hands a chunk to the pipe.  A slot is taken from submit to release; while all `depth` slots are taken the call
 ** waits for the caller's other thread (the one that calls gpumap_pipe_next / gpumap_pipe_release) to free one.  If no
@@ -378,6 +400,10 @@ int gpumap_ann_file_write(const char *filename, const uint8_t *table, int64_t si
 ** as io_stream_set_parser does, src/io.c:232-266) in chunks, maps each chunk on the GPU and
 ** writes one line per located hit to `out_path` (NULL or "-" = stdout):
 **     tag \t name:pos:strand \t score
+** The host cuts the file into chunks (the cut of io_stream_read_seq, src/io.c:196-198) and moves bytes; the chunks
+** are parsed and the lines formatted on the device (GPUMAP_SRC_FILE | GPUMAP_PIPE_LINES).  Environment:
+** GPUMAP_MAPPER_HOST_PARSE=1 parses and formats on the host instead (same output); GPUMAP_CHUNK_BYTES = bytes of input
+** per chunk (default 256 MB, IO_DEFAULT_BUFSIZE, src/io.h:13).
 ** ---------------------------------------------------------------------------------------- */
 int gpumap_mapper(const char *qfile, const gpumap_index *index, gpumap_ctx *ctx, int tau,
                   const char *out_path);
@@ -402,6 +428,9 @@ int gpumap_mapper_multi(const char *qfile, const gpumap_index *index, gpumap_ctx
 **                    score and up to three low bits of the position where that saves a pass; short runs are ordered after)
 **   "verify_tile"    entries of the search's output list a workgroup of k_verify takes (0 = the default, 512; at most 1024) */
 int gpumap_set_option(gpumap_ctx *ctx, const char *name, int64_t value);
+/* The names of the index's sequences (gpumap_index_view.seq_name; txt_pos_to_str prints them, src/index_txt.c:505), for
+** hit lines formatted on the device (GPUMAP_PIPE_LINES).  n_names = seq_cnt of the index. */
+int gpumap_set_seq_names(gpumap_ctx *ctx, const char *const *names, int64_t n_names);
 const char *gpumap_version(void);
 
 #ifdef __cplusplus

@@ -103,6 +103,8 @@ API = {
     "gpumap_batch_stats_ext": (_I, [_P, C.POINTER(_I64)]),
     "gpumap_pipe_create": (_P, [C.POINTER(_P), _I, _I, _I, _I]),
     "gpumap_pipe_try_submit": (_I, [_P, _P, _P, _I64, _P]),
+    "gpumap_set_seq_names": (_I, [_P, _P, _I64]),
+    "gpumap_host_trim": (None, []),
     "gpumap_multi_setup_ms": (C.c_double, [_P, _I]),
     "gpumap_pipe_submit": (_I, [_P, _P, _P, _I64, _P]),
     "gpumap_pipe_close": (None, [_P]),
@@ -130,6 +132,7 @@ API_EXTRA = {
     "gpumap_index_build_codes": (_P, [_P, _P, C.POINTER(C.c_char_p), _I64, C.c_char_p]),
     "gpumap_suffix_sort": (_I, [_P, _I64, _P]),
     "gpumap_reads_dump": (_I64, [C.c_char_p, C.c_size_t, C.c_char_p]),
+    "gpumap_reads_dump_blocks": (_I64, [C.c_char_p, C.c_size_t, C.c_char_p]),
 }
 
 _lib = None

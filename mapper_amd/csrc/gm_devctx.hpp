@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cerrno>
 #include <cstdio>
+#include <mutex>
 #include <vector>
 #include "gm_host.hpp"
 #include "gm_core.hpp"
@@ -91,6 +92,7 @@ struct gpumap_ctx {
    void *noalloc_scratch = nullptr;
    // staging of the batched operators (gpumap_occ_all ...), on the context's own stream
    DevBuf op_in, op_out;
+   DevBuf d_names, d_name_off;        // the sequences' names (gpumap_set_seq_names): hit lines made on the device
    // options read by gpumap_batch_run / gpumap_batch_fetch (batches own their streams, scratch and result arenas)
    bool pinned_results = false;       // "pinned_results": fetch into page-locked arenas of the batch
    bool compact_results = false;      // "compact_results": sorted 8-byte keys + CSR offsets instead of the structure of arrays
@@ -100,6 +102,8 @@ struct gpumap_ctx {
    int64_t jump_budget = 0;           // "jump_bytes": most bytes the jump table may take (0 = a third of the free memory)
    std::vector<int64_t> seq_beg_host; // seq_beg[] (for gpumap_hits_expand)
    hipStream_t pipe_run = nullptr, pipe_copy = nullptr, pipe_up = nullptr;   // streams shared by the batches of pipelines (gm_ctx_pipe_streams)
+   std::mutex spare_mutex;
+   std::vector<gpumap_batch *> spare_batches;     // batch objects of finished pipelines, kept for the next one (gm_ctx_take_batch)
    gpumap_batch *map_batch_obj = nullptr;   // gpumap_map_batch with "pinned_results": the batch whose arenas hold the results
 };
 

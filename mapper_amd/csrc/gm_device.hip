@@ -12,6 +12,7 @@
 #include "gm_kernels.hpp"
 #include "gm_search.hpp"
 #include "gm_ann.hpp"
+#include "gm_parse.hpp"
 
 using namespace gm;
 
@@ -45,6 +46,14 @@ struct gpumap_batch {
    DevBuf hkeys, hkeys_alt, hidx, hidx_alt, hit_read, hit_fp, hit_rp, hit_sz, hit_dp, hit_score, hit_align;
    DevBuf spill, counters, cub_tmp;
    DevBuf read_row, sc_bound, score_add, row_leaves, row_state, sc_qfp, sc_qrp;      // blocksc_trail (gm_batch_run with GM_RUN_SC)
+   // a chunk that came as a block of the read file (GM_SRC_FILE): the ends of its lines, per read where its letters begin
+   // and end in the block and where its tag lies; and the hit lines of a run with GM_RESULT_LINES
+   DevBuf nl_pos, tile_cnt, tile_off, raw_beg, raw_end, tag_off, tag_len, nul_flag, line_len, lines;
+   const int64_t *d_end = nullptr;   // not nullptr: the letters of read r are d_src[d_off[r], d_end[r])
+   bool from_file = false;
+   int lines_per_rec = 0;
+   int64_t first_line = 1, line_bytes = 0;
+   bool have_lines = false;
    DevBuf sc_flags, sc_alias;        // gpumap_ann_build with the reference's reuse of searches (sc_plan)
    struct AnnPlanHost *sc_plan = nullptr;     // not owned; set by gpumap_ann_build around its runs
    int extra_factor = 1;             // the per-query arrays hold room for extra_factor * n_reads queries (2 with sc_plan)
@@ -74,13 +83,13 @@ struct gpumap_batch {
       for (DevBuf *b : {&up_src, &up_off, &seen, &reads, &reads4, &read_len, &len_row, &row_len, &phases, &phase_rec, &phase_lo, &status, &hits, &hit_sizes, &hit_off, &vsteps, &longer, &keys, &keys_alt,
                         &read_cnt, &read_first, &loc_read, &loc_pos, &loc_fwd, &loc_seq, &loc_seqpos, &loc_strand,
                         &loc_score, &hkeys, &hkeys_alt, &hidx, &hidx_alt, &hit_read, &hit_fp, &hit_rp, &hit_sz,
-                        &hit_dp, &hit_score, &hit_align, &spill, &counters, &cub_tmp, &read_row, &sc_bound, &score_add, &row_leaves, &row_state, &sc_qfp, &sc_qrp, &sc_flags, &sc_alias,
+                        &hit_dp, &hit_score, &hit_align, &spill, &counters, &cub_tmp, &read_row, &sc_bound, &score_add, &row_leaves, &row_state, &sc_qfp, &sc_qrp, &sc_flags, &sc_alias, &nl_pos, &tile_cnt, &tile_off, &raw_beg, &raw_end, &tag_off, &tag_len, &nul_flag, &line_len, &lines,
                         &big_idx, &big_dense, &wide_idx, &wide_dense, &vsteps2[0], &vsteps2[1], &stage, &stage2[0], &stage2[1], &iv_idx, &iv_dense, &blk_cnt, &blk_off,
                         &blk_cnt2[0], &blk_cnt2[1], &blk_off2[0], &blk_off2[1]})
          b->release();
       for (auto &e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
       for (hipEvent_t *e : {&ev_seen, &ev_sync, &ev_up}) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
-      for (void *&a : pin_arena) if (a) { (void)hipHostFree(a); a = nullptr; }
+      for (int k = 0; k < 2; k++) if (pin_arena[k]) { gm_pinned_give(pin_arena[k], pin_cap[k]); pin_arena[k] = nullptr; }
       pin_cap[0] = pin_cap[1] = 0;
       if (h_small) { (void)hipHostFree(h_small); h_small = nullptr; }
       if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
@@ -134,6 +143,8 @@ static void *gm_scratch_address(int device)
    return g_scratch_ptr[device];
 }
 
+static void ctx_free_spare_batches(gpumap_ctx *ctx);
+
 int gm_ctx_common_init(gpumap_ctx *ctx, int device)
 {
    hipDeviceProp_t prop;
@@ -157,6 +168,7 @@ extern "C" void gpumap_destroy(gpumap_ctx *ctx)
    (void)hipSetDevice(ctx->device);
    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
    if (ctx->map_batch_obj) { gpumap_batch_free(ctx->map_batch_obj); ctx->map_batch_obj = nullptr; }
+   ctx_free_spare_batches(ctx);
    for (hipStream_t *st : {&ctx->pipe_run, &ctx->pipe_copy, &ctx->pipe_up}) if (*st) { (void)hipStreamSynchronize(*st); (void)hipStreamDestroy(*st); *st = nullptr; }
    if (ctx->owns_index) {
       if (ctx->d_occ) (void)hipFree(ctx->d_occ);
@@ -169,7 +181,7 @@ extern "C" void gpumap_destroy(gpumap_ctx *ctx)
    if (ctx->d_ref_occ) (void)hipFree(ctx->d_ref_occ);
    if (ctx->d_text && ctx->owns_text) (void)hipFree(ctx->d_text);
    if (ctx->d_sym_table) (void)hipFree(ctx->d_sym_table);
-   for (DevBuf *b : {&ctx->op_in, &ctx->op_out}) b->release();
+   for (DevBuf *b : {&ctx->op_in, &ctx->op_out, &ctx->d_names, &ctx->d_name_off}) b->release();
    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
    delete ctx;
 }
@@ -425,6 +437,7 @@ extern "C" int gpumap_set_option(gpumap_ctx *ctx, const char *name, int64_t valu
    else if (!strcmp(name, "verify")) { GM_FAIL_IF(value != -1 && value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 16, "verify out of range (-1, 0, 1, 2, 4, 8, 16)."); ctx->verify = (int)value; }
    else if (!strcmp(name, "sort_all_bits")) ctx->sort_all_bits = value != 0;
    else if (!strcmp(name, "verify_tile")) { GM_FAIL_IF(value < 0 || value > VERIFY_TILE_MAX, "verify_tile out of range (0 = default, at most 1024)."); ctx->verify_tile = (int)value; }
+   else if (!strcmp(name, "trim")) { HIP_TRY(hipSetDevice(ctx->device)); ctx_free_spare_batches(ctx); }
    else if (!strcmp(name, "ann_trail_reuse")) ctx->ann_trail_reuse = value != 0;
    else if (!strcmp(name, "ann_threads")) { GM_FAIL_IF(value < 1, "argument 'threads' must be greater than 0."); ctx->ann_threads = (int)value; }
    else if (!strcmp(name, "jump_k")) { HIP_TRY(hipSetDevice(ctx->device)); GM_FAIL_IF(gm_ctx_build_jump(ctx, (int)value) != 0, "cannot build the jump table."); }
@@ -575,6 +588,30 @@ failure_return:
    return -1;
 }
 
+// The sequences' names for the hit lines made on the device (k_format_write): back to back, with their offsets.
+extern "C" int gpumap_set_seq_names(gpumap_ctx *ctx, const char *const *names, int64_t n_names)
+{
+   GM_FAIL_IF(ctx == nullptr, "argument 'ctx' is NULL.");
+   GM_FAIL_IF(names == nullptr || n_names != ctx->ix.seq_cnt, "one name per sequence of the index.");
+   {
+      std::vector<uint32_t> off((size_t)n_names + 1, 0);
+      std::string blob;
+      for (int64_t i = 0; i < n_names; i++) {
+         GM_FAIL_IF(names[i] == nullptr, "a name is NULL.");
+         blob += names[i];
+         off[(size_t)i + 1] = (uint32_t)blob.size();
+      }
+      HIP_TRY(hipSetDevice(ctx->device));
+      HIP_TRY(ctx->d_names.ensure(blob.size() + 16));
+      HIP_TRY(ctx->d_name_off.ensure(4 * off.size()));
+      HIP_TRY(hipMemcpy(ctx->d_names.p, blob.data(), blob.size(), hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy(ctx->d_name_off.p, off.data(), 4 * off.size(), hipMemcpyHostToDevice));
+   }
+   return 0;
+failure_return:
+   return -1;
+}
+
 extern "C" int gpumap_encode(gpumap_ctx *ctx, const char *text, const int64_t *offsets, int64_t n_reads, uint8_t *codes)
 {
    GM_FAIL_IF(ctx == nullptr, "argument 'ctx' is NULL.");
@@ -609,6 +646,43 @@ extern "C" void gpumap_batch_free(gpumap_batch *b)
    for (hipStream_t st : {b->st_up, b->st_run, b->st_copy}) if (st) (void)hipStreamSynchronize(st);
    b->release();
    delete b;
+}
+
+// Batch objects of finished pipelines stay with their context (device buffers, page-locked block, events and all) and
+// serve the next pipeline: a mapper() call over a few GB of reads otherwise spends as long on allocating and freeing
+// them as on mapping.  gpumap_destroy and option "trim" free them.
+gpumap_batch *gm_ctx_take_batch(gpumap_ctx *ctx)
+{
+   {
+      std::lock_guard<std::mutex> lock(ctx->spare_mutex);
+      if (!ctx->spare_batches.empty()) {
+         gpumap_batch *b = ctx->spare_batches.back();
+         ctx->spare_batches.pop_back();
+         b->st_run = b->st_copy = b->st_up = b->stream;
+         b->sc_plan = nullptr; b->extra_factor = 1; b->ran = false; b->encoded = false; b->n_reads = 0;
+         return b;
+      }
+   }
+   return gpumap_batch_new(ctx);
+}
+
+void gm_ctx_give_batch(gpumap_ctx *ctx, gpumap_batch *b)
+{
+   if (!b) return;
+   (void)hipSetDevice(ctx->device);
+   for (hipStream_t st : {b->st_up, b->st_run, b->st_copy}) if (st) (void)hipStreamSynchronize(st);
+   {
+      std::lock_guard<std::mutex> lock(ctx->spare_mutex);
+      if (ctx->spare_batches.size() < 8) { ctx->spare_batches.push_back(b); return; }
+   }
+   gpumap_batch_free(b);
+}
+
+static void ctx_free_spare_batches(gpumap_ctx *ctx)
+{
+   std::vector<gpumap_batch *> spare;
+   { std::lock_guard<std::mutex> lock(ctx->spare_mutex); spare.swap(ctx->spare_batches); }
+   for (gpumap_batch *b : spare) gpumap_batch_free(b);
 }
 
 extern "C" gpumap_batch *gpumap_batch_new(gpumap_ctx *ctx)
@@ -684,6 +758,7 @@ static int batch_encode(gpumap_ctx *ctx, gpumap_batch *b)
       if (b->st_up != st) HIP_TRY(hipStreamWaitEvent(st, b->ev_up, 0));      // the letters are on the device
       const uint8_t *seen = b->h_small;
       GM_FAIL_IF(seen[SEEN_ERROR] != 0, "offsets must not decrease.");
+      GM_FAIL_IF(b->from_file && seen[SEEN_QUAL] != 0, "inconsistent length of sequence quality.");      // src/seqread.c:47-49
       int64_t maxlen = 1;
       for (int m = 0; m <= MAX_READ; m++) {
          b->length_seen[m] = seen[m] != 0;
@@ -695,7 +770,7 @@ static int batch_encode(gpumap_ctx *ctx, gpumap_batch *b)
       HIP_TRY(b->reads4.ensure((size_t)n_reads * (size_t)(12 * (b->stride / 32))));
       const int64_t groups = n_reads * (b->stride / 32);
       hipLaunchKernelGGL(k_encode, dim3((unsigned)std::min<int64_t>(cdiv(groups, 256), 1 << 22)), dim3(256), 0, st,
-                         b->d_src, b->d_off, b->src_relative ? 1 : 0, n_reads, b->stride,
+                         b->d_src, b->d_off, b->d_end, b->src_relative ? 1 : 0, n_reads, b->stride,
                          b->src_text ? (const uint8_t *)ctx->d_sym_table : (const uint8_t *)nullptr, b->reads.as<uint8_t>(),
                          b->reads4.as<uint32_t>());
       HIP_TRY(hipGetLastError());
@@ -722,11 +797,64 @@ int gm_batch_fill(gpumap_ctx *ctx, gpumap_batch *b, const void *src, const int64
    {
       hipStream_t st = b->st_up;
       b->n_reads = n_reads;
-      b->ran = false; b->have_intervals = false; b->encoded = false;
+      b->ran = false; b->have_intervals = false; b->encoded = false; b->have_lines = false;
       b->src_text = (src_flags & GM_SRC_TEXT) != 0;
+      b->from_file = false; b->d_end = nullptr;
       HIP_TRY(b->read_len.ensure(2 * (size_t)std::max<int64_t>(1, n_reads) * (size_t)b->extra_factor));
       HIP_TRY(b->status.ensure(8 * (size_t)std::max<int64_t>(1, n_reads)));
       int64_t total = 0;
+      if (src_flags & GM_SRC_FILE) {
+         // `src` = a record-aligned block of the read file (host memory), `offsets` = its description (gpumap.h): the
+         // block is copied to the device and parsed there (gm_parse.hpp)
+         GM_FAIL_IF(src_flags & GM_SRC_DEVICE, "a block of a file comes from host memory.");
+         const int64_t bytes = offsets[0], per = offsets[1], n_lines = offsets[2];
+         GM_FAIL_IF(bytes < 0 || bytes >= ((int64_t)1 << 31), "a block of a read file holds fewer than 2 GiB.");
+         GM_FAIL_IF(per != 1 && per != 2 && per != 4, "lines per record: 4 (FASTQ), 2 (FASTA) or 1 (raw).");
+         GM_FAIL_IF(n_lines < 0 || n_reads * per > n_lines, "the block holds fewer lines than its records need.");
+         GM_FAIL_IF(bytes > 0 && src == nullptr, "argument 'src' is NULL.");
+         b->from_file = true; b->src_text = true; b->lines_per_rec = (int)per; b->first_line = offsets[4];
+         const size_t RX = (size_t)std::max<int64_t>(1, n_reads);
+         const int64_t tiles = cdiv(std::max<int64_t>(bytes, 1), LINE_TILE);
+         HIP_TRY(b->up_src.ensure((size_t)bytes + 64));
+         HIP_TRY(b->nl_pos.ensure(4 * (size_t)(n_lines + 1)));
+         HIP_TRY(b->tile_cnt.ensure(4 * (size_t)(tiles + 1)));
+         HIP_TRY(b->tile_off.ensure(4 * (size_t)(tiles + 1)));
+         HIP_TRY(b->raw_beg.ensure(8 * RX)); HIP_TRY(b->raw_end.ensure(8 * RX));
+         HIP_TRY(b->tag_off.ensure(4 * RX)); HIP_TRY(b->tag_len.ensure(4 * RX));
+         HIP_TRY(b->nul_flag.ensure(8));
+         if (bytes > 0) HIP_TRY(hipMemcpyAsync(b->up_src.p, src, (size_t)bytes, hipMemcpyHostToDevice, st));
+         HIP_TRY(hipMemsetAsync(b->seen.p, 0, SEEN_BYTES, st));
+         HIP_TRY(hipMemsetAsync(b->nul_flag.p, 0, 8, st));
+         HIP_TRY(hipMemsetAsync(b->tile_cnt.as<uint32_t>() + tiles, 0, 4, st));
+         if (bytes > 0) {
+            hipLaunchKernelGGL(k_line_count, dim3((unsigned)tiles), dim3(256), 0, st, b->up_src.as<const uint8_t>(), bytes,
+                               b->tile_cnt.as<uint32_t>(), b->nul_flag.as<uint32_t>());
+            size_t tmp = 0;
+            HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, b->tile_cnt.as<uint32_t>(), b->tile_off.as<uint32_t>(), (int)(tiles + 1), st));
+            HIP_TRY(b->cub_tmp.ensure(tmp));
+            HIP_TRY(hipcub::DeviceScan::ExclusiveSum(b->cub_tmp.p, tmp, b->tile_cnt.as<uint32_t>(), b->tile_off.as<uint32_t>(), (int)(tiles + 1), st));
+            hipLaunchKernelGGL(k_line_write, dim3((unsigned)tiles), dim3(256), 0, st, b->up_src.as<const uint8_t>(), bytes,
+                               b->tile_off.as<const uint32_t>(), b->nl_pos.as<uint32_t>(), (uint32_t)(n_lines + 1));
+         } else {
+            HIP_TRY(hipMemsetAsync(b->tile_off.p, 0, 4 * (size_t)(tiles + 1), st));
+         }
+         if (n_reads > 0) {
+            ParseArgs P;
+            P.raw = b->up_src.as<const uint8_t>(); P.n = bytes; P.nl_pos = b->nl_pos.as<const uint32_t>();
+            P.n_nl_dev = b->tile_off.as<const uint32_t>() + tiles; P.nl_cap = n_lines + 1;
+            P.lines_per_rec = (int)per; P.n_rec = n_reads; P.nul_flag = b->nul_flag.as<const uint32_t>();
+            P.beg = b->raw_beg.as<int64_t>(); P.end = b->raw_end.as<int64_t>(); P.read_len = b->read_len.as<uint16_t>();
+            P.seen = b->seen.as<uint8_t>(); P.tag_off = b->tag_off.as<uint32_t>(); P.tag_len = b->tag_len.as<uint32_t>();
+            hipLaunchKernelGGL(k_parse_records, dim3((unsigned)std::min<int64_t>(cdiv(n_reads, 256), 4096)), dim3(256), 0, st, P);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(b->h_small, b->seen.p, SEEN_BYTES, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipEventRecord(b->ev_seen, st));
+         }
+         b->d_src = b->up_src.as<const uint8_t>(); b->d_off = b->raw_beg.as<const int64_t>(); b->d_end = b->raw_end.as<const int64_t>();
+         b->src_relative = false;
+         HIP_TRY(hipEventRecord(b->ev_up, st));
+         return 0;
+      }
       if (src_flags & GM_SRC_DEVICE) {
          GM_FAIL_IF(n_reads > 0 && src == nullptr, "argument 'src' is NULL.");
          b->d_src = (const uint8_t *)src; b->d_off = offsets; b->src_relative = false;
@@ -1289,6 +1417,8 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
       HIP_TRY(hipEventRecord(b->ev[2], st));
       // ---- order: reads in input order, text positions ascending inside a read
       if (L == 0) HIP_TRY(hipMemsetAsync(b->read_first.p, 0, 8 * (size_t)(R + 1), st));
+      b->have_lines = false; b->line_bytes = 0;
+      if (L == 0 && (result_flags & GM_RESULT_LINES)) b->have_lines = true;
       if (L > 0) {
          hipcub::DoubleBuffer<unsigned long long> db(b->keys.as<unsigned long long>(), b->keys_alt.as<unsigned long long>());
          size_t tmp = 0;
@@ -1304,7 +1434,33 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
          HIP_TRY(b->cub_tmp.ensure(tmp));
          HIP_TRY(hipcub::DeviceRadixSort::SortKeys(b->cub_tmp.p, tmp, db, (int)L, begin_bit, end_bit, st));
          b->sorted_keys = db.Current();
-         if (compact) {
+         if (result_flags & GM_RESULT_LINES) {
+            // the lines mapper() prints, made where the keys lie (gm_parse.hpp)
+            GM_FAIL_IF(!b->from_file, "hit lines need a batch that was filled from a block of a read file (its tags).");
+            GM_FAIL_IF(ctx->d_names.p == nullptr, "hit lines need the sequences' names (gpumap_set_seq_names).");
+            if (begin_bit > 0) hipLaunchKernelGGL(k_order_runs, dim3((unsigned)cdiv(L, 256)), dim3(256), 0, st, db.Current(), L, begin_bit);
+            HIP_TRY(b->line_len.ensure(8 * (size_t)(L + 1)));
+            FormatArgs F;
+            F.keys = b->sorted_keys; F.n_keys = L; F.pos_bits = pos_bits; F.n = ctx->ix.n; F.seq_beg = ctx->ix.seq_beg; F.seq_cnt = ctx->ix.seq_cnt;
+            F.names = ctx->d_names.as<const uint8_t>(); F.name_off = ctx->d_name_off.as<const uint32_t>();
+            F.raw = b->up_src.as<const uint8_t>();
+            F.tag_off = b->lines_per_rec > 1 ? b->tag_off.as<const uint32_t>() : nullptr;
+            F.tag_len = b->lines_per_rec > 1 ? b->tag_len.as<const uint32_t>() : nullptr;
+            F.first_line = b->first_line; F.line_len = b->line_len.as<int64_t>(); F.out = nullptr;
+            hipLaunchKernelGGL(k_format_len, dim3((unsigned)cdiv(L + 1, 256)), dim3(256), 0, st, F);
+            size_t t2 = 0;
+            HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, t2, F.line_len, F.line_len, (int)(L + 1), st));
+            HIP_TRY(b->cub_tmp.ensure(t2));
+            HIP_TRY(hipcub::DeviceScan::ExclusiveSum(b->cub_tmp.p, t2, F.line_len, F.line_len, (int)(L + 1), st));
+            int64_t *h_bytes = reinterpret_cast<int64_t *>(host_cnt + CNT_WORDS + CNT_SUMS);
+            HIP_TRY(hipMemcpyAsync(h_bytes, F.line_len + L, 8, hipMemcpyDeviceToHost, st));
+            GM_SYNC(b, st);
+            b->line_bytes = *h_bytes;
+            HIP_TRY(b->lines.ensure((size_t)b->line_bytes + 64));
+            F.out = b->lines.as<uint8_t>();
+            hipLaunchKernelGGL(k_format_write, dim3((unsigned)cdiv(L, 256)), dim3(256), 0, st, F);
+            b->have_lines = true;
+         } else if (compact) {
             hipLaunchKernelGGL(k_read_first, dim3((unsigned)cdiv(L, 256)), dim3(256), 0, st, db.Current(), L, pos_bits, R,
                                b->read_first.as<int64_t>(), begin_bit);
          } else {
@@ -1487,15 +1643,18 @@ int gm_batch_fetch(gpumap_ctx *ctx, gpumap_batch *b, gpumap_hits *out, int resul
       FetchDst d;
       if (result_flags & GM_RESULT_PINNED) {
          size_t need = 16 * 256 + 8 * (size_t)(2 * R + 1) + (compact ? 8 : 42) * (size_t)L + 80 * (size_t)H;
+         if (result_flags & GM_RESULT_LINES) need = 1024 + (size_t)b->line_bytes;
          // two arenas in turn: what a fetch hands out stays valid until the fetch after the next one on this batch
          // (the pipeline releases a slot's result before the slot is used again: one arena there)
          const int k = (result_flags & GM_RESULT_ONE_ARENA) ? 0 : b->pin_turn;
          b->pin_turn ^= 1;
          if (need > b->pin_cap[k]) {
-            if (b->pin_arena[k]) { HIP_TRY(hipHostFree(b->pin_arena[k])); b->pin_arena[k] = nullptr; b->pin_cap[k] = 0; }
+            if (b->pin_arena[k]) { gm_pinned_give(b->pin_arena[k], b->pin_cap[k]); b->pin_arena[k] = nullptr; b->pin_cap[k] = 0; }
             need += need / 4;
-            HIP_TRY(hipHostMalloc(&b->pin_arena[k], need, hipHostMallocDefault));
-            b->pin_cap[k] = need;
+            size_t got = 0;
+            b->pin_arena[k] = gm_pinned_take(need, &got);        // (page-locked blocks go round: gm_reads.cpp)
+            GM_FAIL_IF(b->pin_arena[k] == nullptr, "cannot allocate the result arena.");
+            b->pin_cap[k] = got;
          }
          d.arena = (char *)b->pin_arena[k];
          out->arena = b->pin_arena[k];
@@ -1504,6 +1663,16 @@ int gm_batch_fetch(gpumap_ctx *ctx, gpumap_batch *b, gpumap_hits *out, int resul
       out->ms_search = b->ms[0]; out->ms_locate = b->ms[1]; out->ms_sort = b->ms[2]; out->ms_total = b->ms[3];
       out->key_pos_bits = b->key_pos_bits;
       int rc = 0;
+      if (result_flags & GM_RESULT_LINES) {
+         // the hit lines and nothing else cross the link
+         GM_FAIL_IF(!b->have_lines, "the batch was not run for hit lines.");
+         GM_FAIL_IF(!(result_flags & GM_RESULT_PINNED), "hit lines come in a page-locked arena.");
+         out->line_bytes = b->line_bytes;
+         rc |= fetch_array(d, &out->line_text, b->lines.p, b->line_bytes, st);
+         GM_SYNC(b, st);
+         GM_FAIL_IF(rc != 0, "memory error.");
+         return 0;
+      }
       rc |= fetch_array(d, &out->status, b->status.p, R, st);
       rc |= fetch_array(d, &out->read_first_loc, b->read_first.p, R + 1, st);
       if (compact) {

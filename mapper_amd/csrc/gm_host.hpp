@@ -68,6 +68,7 @@ struct gm_read_chunk {
    std::vector<int64_t>  offsets;  // n+1
    std::vector<uint32_t> tag_off, tag_len;   // FASTQ / FASTA: the tag of read i is raw[tag_off[i], +tag_len[i])
    std::vector<uint64_t> eol;      // scratch: ends of the lines of the block
+   int64_t desc[5] = {0, 0, 0, 0, 0};        // gm_reads_next_block: what GPUMAP_SRC_FILE asks for beside the block (raw)
    int64_t first_line = 1;         // raw format: the tag of read i is its line number, first_line + i
    bool    numbered = false;
    double  t_read = 0, t_parse = 0;   // seconds spent on read() and on parsing for this chunk
@@ -83,7 +84,12 @@ struct gm_read_stream;
 gm_read_stream *gm_reads_open(const char *path);
 // Returns number of reads (0 at EOF, -1 on error); at most `max_bytes` of input per chunk.
 int64_t gm_reads_next(gm_read_stream *s, size_t max_bytes, gm_read_chunk *chunk);
+// The same cut, the block left unparsed in chunk->raw (for the device: GPUMAP_SRC_FILE), chunk->desc filled.
+int64_t gm_reads_next_block(gm_read_stream *s, size_t max_bytes, gm_read_chunk *chunk);
 void gm_reads_close(gm_read_stream *s);
+// Page-locked host blocks that go round (gm_reads.cpp): take one of at least `want` bytes (*cap = its size), give it back.
+void *gm_pinned_take(size_t want, size_t *cap);
+void gm_pinned_give(void *p, size_t cap);
 // fn(t) for t = 0..threads-1 on as many threads (the caller's among them); returns when all are done.
 void gm_parallel_for(int threads, const std::function<void(int)> &fn);
 int gm_host_threads();     // worker threads of the host stages: GPUMAP_HOST_THREADS, else min(16, cores)
@@ -92,11 +98,15 @@ int gm_host_threads();     // worker threads of the host stages: GPUMAP_HOST_THR
 // derive the flags from the context's options, the pipeline brings its own.
 constexpr int GM_RESULT_PINNED = 1, GM_RESULT_COMPACT = 2, GM_RESULT_ONE_ARENA = 4, GM_RUN_SC = 8,
               GM_RUN_NO_LOCATE = 16;      // gm_batch_run: interval hits only (gpumap_ann_build), no located hits
-constexpr int GM_SRC_TEXT = GPUMAP_SRC_TEXT, GM_SRC_DEVICE = GPUMAP_SRC_DEVICE;
+constexpr int GM_RESULT_LINES = 32;       // gm_batch_run / gm_batch_fetch: the located hits as the lines mapper() prints (a batch filled with GM_SRC_FILE)
+constexpr int GM_SRC_TEXT = GPUMAP_SRC_TEXT, GM_SRC_DEVICE = GPUMAP_SRC_DEVICE, GM_SRC_FILE = GPUMAP_SRC_FILE;
 int gm_batch_fill(gpumap_ctx *ctx, gpumap_batch *b, const void *src, const int64_t *offsets, int64_t n_reads, int src_flags, bool encode_now);
 int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, int result_flags);
 int gm_batch_fetch(gpumap_ctx *ctx, gpumap_batch *b, gpumap_hits *out, int result_flags);
 // The streams a batch puts its work on (HIP streams as void *: this header is host-only): the run's kernels,
 // the copy of the results to the host, the uploads.  A pipeline shares three streams per context among its batches.
+// Batch objects that go round between the pipelines of one context (gm_device.hip).
+gpumap_batch *gm_ctx_take_batch(gpumap_ctx *ctx);
+void gm_ctx_give_batch(gpumap_ctx *ctx, gpumap_batch *b);
 void gm_batch_set_streams(gpumap_batch *b, void *run, void *copy, void *up);
 int  gm_ctx_pipe_streams(gpumap_ctx *ctx, void **run, void **copy, void **up);

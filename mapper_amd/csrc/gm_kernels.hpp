@@ -228,7 +228,8 @@ __global__ void __launch_bounds__(256) k_read_lengths(const int64_t *offsets, in
 // words that hold them (a word that holds a letter of the buffer lies inside the buffer's pages) and brought
 // into place with v_alignbit; `table` (sym_table of the index, 256 entries) sits in LDS.  table = nullptr: src
 // holds codes already (values above 4 become N, as sym_index does for characters it does not know).
-__global__ void __launch_bounds__(256) k_encode(const uint8_t *src, const int64_t *offsets, int relative, int64_t n_reads, int stride,
+// ends (or nullptr): the letters of read r are src[offsets[r], ends[r]) (reads parsed out of a block of a file, gm_parse.hpp).
+__global__ void __launch_bounds__(256) k_encode(const uint8_t *src, const int64_t *offsets, const int64_t *ends, int relative, int64_t n_reads, int stride,
                                                 const uint8_t *table, uint8_t *dst, uint32_t *planes)
 {
    __shared__ uint8_t s_tab[256];
@@ -242,7 +243,7 @@ __global__ void __launch_bounds__(256) k_encode(const uint8_t *src, const int64_
       // where the batch allows it: the 64-bit division was a third of the kernel's instructions)
       const int64_t r = (gpr & (gpr - 1)) == 0 ? t >> (31 - __clz(gpr)) : (t < ((int64_t)1 << 32) ? (int64_t)((uint32_t)t / (uint32_t)gpr) : t / gpr);
       const int g = (int)(t - r * gpr);
-      const int64_t beg = offsets[r], len = offsets[r + 1] - beg;
+      const int64_t beg = offsets[r], len = (ends ? ends[r] : offsets[r + 1]) - beg;
       int64_t k64 = len - 32 * (int64_t)g;
       const int k = k64 < 0 ? 0 : (k64 > 32 ? 32 : (int)k64);    // letters of the read in this group
       uint32_t c[8];

@@ -5,10 +5,14 @@
 // its own, over one or several GPUs), the calling thread takes the results in input order, formats and writes
 // them (txt_pos_to_str's "name:pos:strand", src/index_txt.c:480-511, from the compact keys: strand and
 // coordinates by the rule of :492-505 with seq_bisect :770-787).  Host code only: no HIP in this file.
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE
+#endif
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <chrono>
+#include <climits>
 #include <condition_variable>
 #include <cstring>
 #include <deque>
@@ -143,12 +147,13 @@ static int mapper_run(const char *qfile, const gpumap_index *index, gpumap_ctx *
    gm_read_stream *in = nullptr;
    int fo = -1;
    bool fo_regular = false, fo_own = false;
-   int64_t fo_off = 0;
+   int64_t fo_off = 0, fo_alloc = 0;      // bytes written; bytes whose blocks are allocated
    gpumap_pipe *pipe = nullptr;
    Chan spare(256);              // chunk objects go round, their buffers are allocated once
    std::thread reader;
    int reader_rc = 0, writer_rc = 0;
    bool failed = false;
+   const double t_enter = now_s();
    GM_FAIL_IF(qfile == nullptr, "argument 'qfile' is NULL.");
    GM_FAIL_IF(index == nullptr, "argument 'index' is NULL.");
    GM_FAIL_IF(ctxs == nullptr || n_ctx < 1 || ctxs[0] == nullptr, "argument 'ctx' is NULL.");
@@ -167,9 +172,16 @@ static int mapper_run(const char *qfile, const gpumap_index *index, gpumap_ctx *
    {
       // per GPU: one chunk on its way in, one being searched, one on its way out or being written
       const int depth = 3;
-      pipe = gpumap_pipe_create(ctxs, n_ctx, depth, tau, GPUMAP_SRC_TEXT | GPUMAP_PIPE_COMPACT);
-      GM_FAIL_IF(pipe == nullptr, "cannot set up the pipeline.");
+      // The chunks go to the device as the blocks of the file they are (parsed there, gm_parse.hpp) and come back as the
+      // lines to write: the host only moves bytes.  GPUMAP_MAPPER_HOST_PARSE=1: the host parses the chunks and formats
+      // the lines from compact keys (the earlier form; same output, kept for comparison).
+      const bool on_device = !(getenv("GPUMAP_MAPPER_HOST_PARSE") && atoi(getenv("GPUMAP_MAPPER_HOST_PARSE")) != 0);
       const gpumap_index_view &v = index->view;
+      if (on_device)
+         for (int i = 0; i < n_ctx; i++)
+            GM_FAIL_IF(gpumap_set_seq_names(ctxs[i], v.seq_name, v.seq_cnt) != 0, "cannot hand the sequences' names to the device.");
+      pipe = gpumap_pipe_create(ctxs, n_ctx, depth, tau, on_device ? (GPUMAP_SRC_FILE | GPUMAP_PIPE_LINES) : (GPUMAP_SRC_TEXT | GPUMAP_PIPE_COMPACT));
+      GM_FAIL_IF(pipe == nullptr, "cannot set up the pipeline.");
       std::vector<size_t> name_len((size_t)v.seq_cnt);
       for (int64_t i = 0; i < v.seq_cnt; i++) name_len[(size_t)i] = strlen(v.seq_name[i]);
       size_t chunk_bytes = (size_t)256 << 20;                     // IO_DEFAULT_BUFSIZE, src/io.h:13
@@ -182,6 +194,7 @@ static int mapper_run(const char *qfile, const gpumap_index *index, gpumap_ctx *
       for (int i = 0; i < n_jobs; i++) {
          Job *j = new Job();
          j->chunk.text.pinned = true;                             // uploaded from where the parser writes it
+         j->chunk.raw.pinned = on_device;                         // ... from where the file is read to
          spare.push(j);
       }
       reader = std::thread([&] {
@@ -189,11 +202,13 @@ static int mapper_run(const char *qfile, const gpumap_index *index, gpumap_ctx *
             Job *j = spare.pop();
             if (j == nullptr) break;
             memset(&j->h, 0, sizeof j->h);
-            j->n = gm_reads_next(in, chunk_bytes, &j->chunk);
+            j->n = on_device ? gm_reads_next_block(in, chunk_bytes, &j->chunk) : gm_reads_next(in, chunk_bytes, &j->chunk);
             t_read += j->chunk.t_read; t_parse += j->chunk.t_parse;
             if (j->n <= 0) { reader_rc = j->n < 0 ? -1 : 0; delete j; break; }
             fprintf(stderr, "read: %ld sequences.\n", (long)j->n);                 // src/mapper.c:30
-            if (gpumap_pipe_submit(pipe, j->chunk.text.data(), j->chunk.offsets.data(), j->n, j) != 0) { delete j; reader_rc = -1; break; }
+            const int rc = on_device ? gpumap_pipe_submit(pipe, j->chunk.raw.data(), j->chunk.desc, j->n, j)
+                                     : gpumap_pipe_submit(pipe, j->chunk.text.data(), j->chunk.offsets.data(), j->n, j);
+            if (rc != 0) { delete j; reader_rc = -1; break; }
          }
          gpumap_pipe_close(pipe);
       });
@@ -210,9 +225,32 @@ static int mapper_run(const char *qfile, const gpumap_index *index, gpumap_ctx *
          j->h = h;
          const int64_t L = h.n_locs;
          const double w0 = now_s();
-         gm_parallel_for(T, [&](int t) { format_range(*j, v, name_len, L * t / T, L * (t + 1) / T, parts[(size_t)t]); });
+         if (!on_device) gm_parallel_for(T, [&](int t) { format_range(*j, v, name_len, L * t / T, L * (t + 1) / T, parts[(size_t)t]); });
          const double w1 = now_s();
-         if (fo_regular) {
+         if (on_device) {
+            // the lines as they came from the device, slices of them written side by side
+            // (buffered writes to one file take the inode's lock one at a time on ext4: 7 GB/s with 16 threads on this
+            // platform, 12 GB/s into blocks allocated beforehand, tools/write_bench.cpp; so a few threads, and the
+            // blocks of the next GiB allocated ahead of the writes, keeping the file's size)
+            const int64_t B = h.line_bytes;
+            if (fo_regular && fo_off + B > fo_alloc) {
+#ifdef FALLOC_FL_KEEP_SIZE
+               const int64_t step = std::max<int64_t>((int64_t)1 << 30, 2 * B);
+               if (fallocate(fo, FALLOC_FL_KEEP_SIZE, (off_t)fo_alloc, (off_t)(fo_off + step - fo_alloc)) == 0) fo_alloc = fo_off + step;
+               else fo_alloc = INT64_MAX;                  // (not supported here: no further attempts)
+#endif
+            }
+            const int TW = std::min(T, 4);
+            if (fo_regular && B >= ((int64_t)4 << 20)) {
+               std::vector<int> bad((size_t)TW, 0);
+               gm_parallel_for(TW, [&](int t) {
+                  const int64_t a = B * t / TW, e = B * (t + 1) / TW;
+                  if (e > a && write_all(fo, h.line_text + a, (size_t)(e - a), fo_off + a) != 0) bad[(size_t)t] = 1;
+               });
+               for (int x : bad) if (x) writer_rc = -1;
+            } else if (B > 0 && write_all(fo, h.line_text, (size_t)B, fo_regular ? fo_off : -1) != 0) writer_rc = -1;
+            fo_off += B;
+         } else if (fo_regular) {
             std::vector<int64_t> at((size_t)T + 1, fo_off);
             for (int t = 0; t < T; t++) at[(size_t)t + 1] = at[(size_t)t] + (int64_t)parts[(size_t)t].size();
             std::vector<int> bad((size_t)T, 0);
@@ -246,15 +284,22 @@ static int mapper_run(const char *qfile, const gpumap_index *index, gpumap_ctx *
       reader.join();
       spare.drain();
       if (getenv("GPUMAP_MAPPER_VERBOSE"))
-         fprintf(stderr, "mapper stages (s): reader read %.3f parse %.3f | writer wait-for-gpu %.3f format %.3f write %.3f | wall %.3f\n",
-                 t_read, t_parse, t_wait, t_format, t_write, now_s() - t_begin);
+         fprintf(stderr, "mapper stages (s): set-up %.3f | reader read %.3f parse %.3f | writer wait-for-gpu %.3f format %.3f write %.3f | wall %.3f\n",
+                 t_begin - t_enter, t_read, t_parse, t_wait, t_format, t_write, now_s() - t_enter);
    }
    GM_FAIL_IF(failed, "batch failed.");
    GM_FAIL_IF(reader_rc != 0, "error while reading the read file.");
    GM_FAIL_IF(writer_rc != 0, "error while writing the output.");
-   gpumap_pipe_destroy(pipe);
-   if (fo_own) close(fo);
-   gm_reads_close(in);
+   {
+      const double t0 = now_s();
+      gpumap_pipe_destroy(pipe);
+      if (fo_own) {
+         if (fo_regular && fo_alloc > fo_off && fo_alloc != INT64_MAX) (void)ftruncate(fo, (off_t)fo_off);      // gives back the blocks allocated ahead
+         close(fo);
+      }
+      gm_reads_close(in);
+      if (getenv("GPUMAP_MAPPER_VERBOSE")) fprintf(stderr, "mapper tear-down %.3f s, whole call %.3f s\n", now_s() - t0, now_s() - t_enter);
+   }
    return 0;
 failure_return:
    if (reader.joinable()) { spare.close(); if (pipe) gpumap_pipe_close(pipe); reader.join(); }

@@ -100,7 +100,7 @@ extern "C" void gpumap_pipe_destroy(gpumap_pipe *p)
    p->cv.notify_all();
    for (auto &s : p->slots) {
       if (s.worker.joinable()) s.worker.join();
-      gpumap_batch_free(s.batch);
+      if (s.batch) gm_ctx_give_batch(s.ctx, s.batch);
    }
    delete p;
 }
@@ -112,12 +112,15 @@ extern "C" gpumap_pipe *gpumap_pipe_create(gpumap_ctx *const *ctxs, int n_ctx, i
    for (int i = 0; i < n_ctx; i++) GM_FAIL_IF(ctxs[i] == nullptr, "a context is NULL.");
    GM_FAIL_IF(depth < 1 || depth > 16, "depth out of range (1..16).");
    GM_FAIL_IF(tau < 0 || tau > GPUMAP_MAX_TAU, "argument 'tau' out of range.");
-   GM_FAIL_IF(flags & ~(GPUMAP_SRC_TEXT | GPUMAP_SRC_DEVICE | GPUMAP_PIPE_COMPACT), "unknown flag.");
+   GM_FAIL_IF(flags & ~(GPUMAP_SRC_TEXT | GPUMAP_SRC_DEVICE | GPUMAP_SRC_FILE | GPUMAP_PIPE_COMPACT | GPUMAP_PIPE_LINES), "unknown flag.");
    GM_FAIL_IF((flags & GPUMAP_SRC_DEVICE) && n_ctx > 1, "device-resident chunks belong to one GPU: one context.");
+   GM_FAIL_IF((flags & GPUMAP_SRC_FILE) && (flags & GPUMAP_SRC_DEVICE), "blocks of a read file come from host memory.");
+   GM_FAIL_IF((flags & GPUMAP_PIPE_LINES) && !(flags & GPUMAP_SRC_FILE), "hit lines need the blocks of the read file (GPUMAP_SRC_FILE: the tags).");
    p = new gpumap_pipe();
    p->tau = tau;
-   p->src_flags = flags & (GPUMAP_SRC_TEXT | GPUMAP_SRC_DEVICE);
-   p->result_flags = GM_RESULT_PINNED | GM_RESULT_ONE_ARENA | ((flags & GPUMAP_PIPE_COMPACT) ? GM_RESULT_COMPACT : 0);
+   p->src_flags = flags & (GPUMAP_SRC_TEXT | GPUMAP_SRC_DEVICE | GPUMAP_SRC_FILE);
+   p->result_flags = GM_RESULT_PINNED | GM_RESULT_ONE_ARENA |
+                     ((flags & GPUMAP_PIPE_LINES) ? GM_RESULT_LINES : ((flags & GPUMAP_PIPE_COMPACT) ? GM_RESULT_COMPACT : 0));
    p->slots = std::vector<Slot>((size_t)depth * (size_t)n_ctx);
    p->ctx_submitted.assign((size_t)n_ctx, 0);
    p->ctx_turn.assign((size_t)n_ctx, 0);
@@ -127,7 +130,7 @@ extern "C" gpumap_pipe *gpumap_pipe_create(gpumap_ctx *const *ctxs, int n_ctx, i
       Slot &s = p->slots[i];
       s.ctx = ctxs[i % (size_t)n_ctx];                   // consecutive chunks go to different GPUs
       s.ctx_index = (int)(i % (size_t)n_ctx);
-      s.batch = gpumap_batch_new(s.ctx);
+      s.batch = gm_ctx_take_batch(s.ctx);
       GM_FAIL_IF(s.batch == nullptr, "cannot create a batch.");
       void *run = nullptr, *copy = nullptr, *up = nullptr;
       GM_FAIL_IF(gm_ctx_pipe_streams(s.ctx, &run, &copy, &up) != 0, "cannot create the streams of the pipeline.");

@@ -85,3 +85,69 @@ def test_mapper_ragged_reads_and_errors(workdir):
         ctx.mapper(os.path.join(workdir, "missing.fastq"), index, 2, bad + ".out")
     ctx.close()
     index.close()
+
+
+@pytest.mark.parametrize("fmt", ["fastq", "fasta", "raw"])
+def test_device_parsing_and_formatting_equal_the_host_path(workdir, fmt, monkeypatch):
+    """gpumap_mapper parses the chunks and formats the lines on the device (gm_parse.hpp); with GPUMAP_MAPPER_HOST_PARSE=1
+    the host does both (gm_reads.cpp, checked against the line-by-line model of the reference's reader in
+    tests/test_host.py).  Files with what the reader's rules are about: NULs inside tags and sequences (a line's content
+    ends there), CRs, empty lines and empty reads, tags of every length, a last record that is incomplete, a last line
+    without newline; cut into chunks of several sizes.  Both paths write the same bytes."""
+    base, seqs = common.synth_index(workdir, "rnd300k", 300_000, seed=21, n_seqs=3)
+    codes, offs = synth.make_reads(seqs, 4000, 100, 2, seed=78, n_frac=0.01)
+    codes = codes.reshape(-1)
+    rng = np.random.default_rng(9)
+    recs = []
+    for i in range(len(offs) - 1):
+        m = 100 if rng.random() < 0.8 else int(rng.integers(0, 101))
+        s = LETTERS[codes[offs[i]:offs[i] + m]].tobytes()
+        u = rng.random()
+        if u < 0.03 and m > 40:
+            s = s[:40] + b"\0" + s[41:]                       # the read ends at the NUL
+        elif u < 0.06:
+            s = s + b"\r"                                     # a CR is a letter like any other unknown one
+        tag = b"r%d" % i + b" x" * int(rng.integers(0, 30))
+        if rng.random() < 0.02:
+            tag = tag[:2] + b"\0" + tag[2:]
+        if rng.random() < 0.01:
+            tag = b""
+        if fmt == "fastq":
+            recs += [b"@" + tag if rng.random() < 0.99 else b"", s, b"+" + (b"anything" if rng.random() < 0.1 else b""), b"I" * len(s.split(b"\0")[0])]
+        elif fmt == "fasta":
+            recs += [b">" + tag, s]
+        else:
+            recs += [s if i or not s.startswith((b"@", b">")) else b"A" + s]
+    for variant, data in (("whole", b"\n".join(recs) + b"\n"), ("open", b"\n".join(recs)), ("cut", b"\n".join(recs[:-1]) + b"\n")):
+        qfile = os.path.join(workdir, "tricky_%s.%s" % (variant, fmt))
+        open(qfile, "wb").write(data)
+        index = ma.HostIndex.read(base)
+        ctx = ma.Context.from_index(index, 0)
+        for chunk_bytes in ("1", "777", "50000", "100000000"):
+            monkeypatch.setenv("GPUMAP_CHUNK_BYTES", chunk_bytes)
+            monkeypatch.setenv("GPUMAP_MAPPER_HOST_PARSE", "1")
+            ctx.mapper(qfile, index, 2, qfile + ".host")
+            monkeypatch.setenv("GPUMAP_MAPPER_HOST_PARSE", "0")
+            ctx.mapper(qfile, index, 2, qfile + ".dev")
+            a, b = open(qfile + ".host", "rb").read(), open(qfile + ".dev", "rb").read()
+            assert a == b, (variant, chunk_bytes, len(a), len(b))
+            assert a.count(b"\n") > 2500
+            if chunk_bytes == "1" and variant == "whole":
+                break                                        # (a chunk per record: once is enough)
+        ctx.close()
+        index.close()
+
+
+def test_device_path_reports_a_bad_quality_line_in_a_later_chunk(workdir, monkeypatch):
+    base, seqs = common.synth_index(workdir, "rnd300k", 300_000, seed=21, n_seqs=3)
+    index = ma.HostIndex.read(base)
+    ctx = ma.Context.from_index(index, 0)
+    bad = os.path.join(workdir, "bad_later.fastq")
+    with open(bad, "w") as f:
+        for i in range(200):
+            f.write("@r%d\nACGTACGTACGTACGTACGTACGTACGT\n+\n%s\n" % (i, "I" * (28 if i != 150 else 27)))
+    monkeypatch.setenv("GPUMAP_CHUNK_BYTES", "2000")
+    with pytest.raises(ma.GpumapError):
+        ctx.mapper(bad, index, 2, bad + ".out")
+    ctx.close()
+    index.close()

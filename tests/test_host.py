@@ -250,6 +250,35 @@ def test_block_reader_against_line_by_line_model(workdir, threads, monkeypatch):
             exp = b"#chunk\n".join(b"".join(t + b"\t" + q + b"\n" for t, q in c) for c in want)
             assert n == sum(len(c) for c in want), (case, fmt, max_bytes)
             assert got == exp, (case, fmt, max_bytes)
+            # the same cut, blocks left unparsed for the device (gm_reads_next_block): every block parsed by the model's
+            # rules gives the chunk's reads, and its description says what it holds
+            n2 = ma.lib().gpumap_reads_dump_blocks(path.encode(), max_bytes, (path + ".blocks").encode())
+            assert n2 == n, (case, fmt, max_bytes)
+            blob, at, lineno = open(path + ".blocks", "rb").read(), 0, 1
+            for c in want:
+                e = blob.index(b"\n", at)
+                head = blob[at:e].split()
+                assert head[0] == b"#block"
+                n_rec, nbytes, per, n_lines, first = (int(x) for x in head[1:])
+                block = blob[e + 1:e + 1 + nbytes]
+                at = e + 1 + nbytes
+                assert (n_rec, first) == (len(c), lineno), (case, fmt, max_bytes)
+                lines = block.split(b"\n")
+                if lines and lines[-1] == b"":
+                    lines.pop()
+                assert len(lines) == n_lines and per == {"fastq": 4, "fasta": 2, "raw": 1}[fmt] and n_rec == n_lines // per
+                lineno += n_lines
+
+                def content(b):
+                    z = b.find(b"\0")
+                    return b if z < 0 else b[:z]
+                for r, (tag, seq) in enumerate(c):
+                    assert content(lines[per * r + (0 if per == 1 else 1)]) == seq
+                    if per > 1:
+                        assert content(lines[per * r])[1:] == tag
+                    else:
+                        assert str(first + r).encode() == tag
+            assert at == len(blob)
 
 
 # ---------------------------------------------------------------- shared kernel core on the host

@@ -60,6 +60,8 @@ def main():
     if not os.environ.get("GPUMAP_MAPPER_VERBOSE"): os.dup2(devnull, 2)                                       # "read: N sequences." per chunk
     try:
         for _ in range(args.repeats):
+            if os.path.exists(out):
+                os.remove(out)                      # a new output file every time, as a new run has (truncating 5 GB of dirty pages is the file system's time)
             t0 = time.perf_counter()
             ctx.mapper(qfile, index, args.tau, out)
             dt = time.perf_counter() - t0
