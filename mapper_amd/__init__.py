@@ -56,6 +56,7 @@ class _Hits(C.Structure):
         ("n_ext", C.c_int64), ("ms_search", C.c_float), ("ms_locate", C.c_float), ("ms_sort", C.c_float),
         ("ms_total", C.c_float), ("arena", C.c_void_p),
         ("loc_key", C.POINTER(C.c_uint64)), ("key_pos_bits", C.c_int32), ("expanded", C.c_int32),
+        ("line_text", C.c_void_p), ("line_bytes", C.c_int64),
     ]
 
 

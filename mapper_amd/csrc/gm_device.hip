@@ -673,7 +673,8 @@ void gm_ctx_give_batch(gpumap_ctx *ctx, gpumap_batch *b)
    for (hipStream_t st : {b->st_up, b->st_run, b->st_copy}) if (st) (void)hipStreamSynchronize(st);
    {
       std::lock_guard<std::mutex> lock(ctx->spare_mutex);
-      if (ctx->spare_batches.size() < 8) { ctx->spare_batches.push_back(b); return; }
+      static const bool keep = !(getenv("GPUMAP_KEEP_BATCHES") && atoi(getenv("GPUMAP_KEEP_BATCHES")) == 0);
+      if (keep && ctx->spare_batches.size() < 8) { ctx->spare_batches.push_back(b); return; }
    }
    gpumap_batch_free(b);
 }

@@ -45,6 +45,17 @@ def test_header_is_c99_and_the_integration_sketch_compiles_against_the_reference
         r = subprocess.run([gcc, "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", inc, f.name],
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
+    # the structs the python binding mirrors have the size and the field offsets the C header gives them (a field added
+    # to one side only makes the library write past the other's allocation)
+    with tempfile.TemporaryDirectory() as d:
+        src, exe = os.path.join(d, "sz.c"), os.path.join(d, "sz")
+        open(src, "w").write('#include <stdio.h>\n#include <stddef.h>\n#include "gpumap.h"\nint main(void) { printf("%zu %zu %zu %zu %zu\\n", '
+                             'sizeof(gpumap_hits), offsetof(gpumap_hits, loc_key), offsetof(gpumap_hits, line_bytes), sizeof(gpumap_index_view), '
+                             'sizeof(gpumap_devindex)); return 0; }\n')
+        r = subprocess.run([gcc, "-std=c99", "-I", inc, src, "-o", exe], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        sizes = [int(x) for x in subprocess.run([exe], capture_output=True, text=True).stdout.split()]
+    assert sizes == [C.sizeof(ma._Hits), ma._Hits.loc_key.offset, ma._Hits.line_bytes.offset, C.sizeof(ma.IndexView), C.sizeof(ma.DevIndex)]
     ref = "/root/reference/src"
     if not os.path.isfile(os.path.join(ref, "mapper.h")):
         pytest.skip("the reference's headers are not on this machine")
