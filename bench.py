@@ -346,8 +346,10 @@ def main():
                     "frac_hbm": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else None, "accounting": note_}
         kernels = [
             kern("k_search", k_ms, occ_steps, "extension step on the Occ table", 128, "two 64-B Occ lines per step (SURVEY 8d)"),
-            kern("k_verify + k_verify_group", mean["k_verify"], W, "suffix replayed on the text", 216,
-                 "64 B suffix-array line + 64 B text window + 48 B query planes + 32 B list entry + 8 B key of a hit (upper bound: one per suffix)"),
+            kern("k_verify + k_verify_group", mean["k_verify"], W, "suffix replayed on the text", 128.0 + 80.0 * c["n_hits"] / max(W, 1),
+                 "per suffix one 64-B line of the suffix array and one of the text's bit planes (SURVEY 8d: 64 B per random touch); per entry "
+                 "of the search's list, read once, 32 B + 48 B of the query's planes; the counters of the committed PMC passes "
+                 "(pmc_bytes, pmc_frac_hbm) are the check of this figure"),
             kern("k_stage_compact + scan + k_place + k_place_long", mean["locate"], L, "located position", 16,
                  "8-B key read from the blocks' staging slots and written to the dense array (the few hits that are intervals read "
                  "their suffix-array entries instead; not counted apart)"),
@@ -356,6 +358,12 @@ def main():
             kern("k_encode + k_pack_planes", mean["encode"], n_reads * w["m"], "letter", 2.375,
                  "1 B letter in, 1 B code out, 3 bits of planes"),
         ]
+        vt = pmc_verify_traffic(args.workload)
+        if vt:
+            kernels[1]["pmc_bytes"] = vt["bytes"]
+            kernels[1]["pmc_ms"] = vt["ms"]
+            kernels[1]["pmc_frac_hbm"] = vt["bytes"] / (vt["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS if vt["ms"] else None
+            kernels[1]["pmc_source"] = vt["source"]
         out = {
             "metric": "reads mapped/sec (node), GRCh38-size index, %dnt <=%d mm; %% HBM gather roofline" % (w["m"], w["tau"])
                       if args.workload.startswith("grch38") else
@@ -497,7 +505,7 @@ def pmc_traffic(workload):
     WRITE_SIZE) * 1024.  FETCH_SIZE = TCC_EA0_RDREQ * 64 B here (every request of this kernel is one
     64-byte line, TCC_EA0_RDREQ_32B = 0), so the factor 2 of wide coalesced streams does not apply
     (MI355X_MICROARCH.md, HBM).  None when no profile of this workload is committed."""
-    for rnd in ("r2", "r1"):
+    for rnd in ("r3", "r2", "r1"):
         path = os.path.join(ROOT, "profiles", "%s_%s_profile_summary.json" % (rnd, workload))
         try:
             pm = json.load(open(path))["pmc_per_launch"]
@@ -527,6 +535,27 @@ def cpu_share():
     if os.environ.get("OMP_NUM_THREADS", "").isdigit():
         share = min(share, int(os.environ["OMP_NUM_THREADS"]))          # the box's CPU share per GPU job
     return share
+
+
+def pmc_verify_traffic(workload):
+    """FETCH_SIZE + WRITE_SIZE and the kernel time of k_verify and k_verify_group per chunk from the committed PMC passes
+    (tools/profile_passes.sh), or None."""
+    for rnd in ("r3", "r2"):
+        path = os.path.join(ROOT, "profiles", "%s_%s_profile_summary.json" % (rnd, workload))
+        try:
+            d = json.load(open(path))
+            by, ms = 0.0, 0.0
+            for name, v in d["pmc_per_launch"].items():
+                if "gm::k_verify" in name:
+                    by += (v["FETCH_SIZE"]["avg"] + v["WRITE_SIZE"]["avg"]) * 1024.0
+            for v in d["kernel_stats"]:
+                if "gm::k_verify" in v["kernel"]:
+                    ms += v["avg_ns"] * 1e-6                      # (one launch of each instance per chunk)
+            if by > 0 and ms > 0:
+                return {"bytes": by, "ms": ms, "source": os.path.relpath(path, ROOT)}
+        except Exception:
+            continue
+    return None
 
 
 def cpu_baseline(ctx, base, codes, offs, w, seconds, gpu_ctx=None):

@@ -54,6 +54,7 @@ struct gpumap_batch {
    int lines_per_rec = 0;
    int64_t first_line = 1, line_bytes = 0;
    bool have_lines = false;
+   DevBuf big_start, big_cnt;        // k_order_first: the runs of keys it left to k_order_big
    DevBuf sc_flags, sc_alias;        // gpumap_ann_build with the reference's reuse of searches (sc_plan)
    struct AnnPlanHost *sc_plan = nullptr;     // not owned; set by gpumap_ann_build around its runs
    int extra_factor = 1;             // the per-query arrays hold room for extra_factor * n_reads queries (2 with sc_plan)
@@ -83,7 +84,7 @@ struct gpumap_batch {
       for (DevBuf *b : {&up_src, &up_off, &seen, &reads, &reads4, &read_len, &len_row, &row_len, &phases, &phase_rec, &phase_lo, &status, &hits, &hit_sizes, &hit_off, &vsteps, &longer, &keys, &keys_alt,
                         &read_cnt, &read_first, &loc_read, &loc_pos, &loc_fwd, &loc_seq, &loc_seqpos, &loc_strand,
                         &loc_score, &hkeys, &hkeys_alt, &hidx, &hidx_alt, &hit_read, &hit_fp, &hit_rp, &hit_sz,
-                        &hit_dp, &hit_score, &hit_align, &spill, &counters, &cub_tmp, &read_row, &sc_bound, &score_add, &row_leaves, &row_state, &sc_qfp, &sc_qrp, &sc_flags, &sc_alias, &nl_pos, &tile_cnt, &tile_off, &raw_beg, &raw_end, &tag_off, &tag_len, &nul_flag, &line_len, &lines,
+                        &hit_dp, &hit_score, &hit_align, &spill, &counters, &cub_tmp, &read_row, &sc_bound, &score_add, &row_leaves, &row_state, &sc_qfp, &sc_qrp, &sc_flags, &sc_alias, &big_start, &big_cnt, &nl_pos, &tile_cnt, &tile_off, &raw_beg, &raw_end, &tag_off, &tag_len, &nul_flag, &line_len, &lines,
                         &big_idx, &big_dense, &wide_idx, &wide_dense, &vsteps2[0], &vsteps2[1], &stage, &stage2[0], &stage2[1], &iv_idx, &iv_dense, &blk_cnt, &blk_off,
                         &blk_cnt2[0], &blk_cnt2[1], &blk_off2[0], &blk_off2[1]})
          b->release();
@@ -1427,14 +1428,26 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
          // pass (GRCh38 size with 12.5 M reads: 61 bits, 56 without the score and one bit), the sort starts above
          // them and k_order_runs puts the short runs of keys that agree above in order.
          const int end_bit = pos_bits + 4 + read_bits;
+         // Round 3: the radix sort runs over the read's bits only (3 passes for 12.5 M reads instead of 7 over the key):
+         // the hits of a read come together, and k_order_first / k_order_big put each read's hits in order where they
+         // lie (3.3 per read on average at GRCh38 size).  Option "sort_all_bits": one sort over the whole key.
+         // (end_bit = 64 with begin_bit > 0: hipcub returns unsorted keys for 10^4 .. 10^6 items, tools/sortpairs_check.hip)
          int begin_bit = 0;
-         for (int drop = 0; drop <= 3 && begin_bit == 0; drop++)
-            if (cdiv(end_bit - (4 + drop), 8) < cdiv(end_bit, 8) && !ctx->sort_all_bits && end_bit < 64) begin_bit = 4 + drop;   // (end_bit = 64 with
-                                                                          // begin_bit > 0: hipcub returns unsorted keys for 10^4 .. 10^6 items, tools/sortpairs_check.hip)
+         if (!ctx->sort_all_bits && end_bit < 64) begin_bit = pos_bits + 4;
          HIP_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp, db, (int)L, begin_bit, end_bit, st));
          HIP_TRY(b->cub_tmp.ensure(tmp));
          HIP_TRY(hipcub::DeviceRadixSort::SortKeys(b->cub_tmp.p, tmp, db, (int)L, begin_bit, end_bit, st));
          b->sorted_keys = db.Current();
+         if (begin_bit > 0) {
+            const int64_t ob = cdiv(L, 256);
+            HIP_TRY(b->big_start.ensure(4 * (size_t)ORDER_SLOT * (size_t)ob));
+            HIP_TRY(b->big_cnt.ensure(4 * (size_t)ob));
+            hipLaunchKernelGGL(k_order_first, dim3((unsigned)ob), dim3(256), 0, st, db.Current(), L, begin_bit, b->big_start.as<uint32_t>(),
+                               b->big_cnt.as<uint32_t>());
+            hipLaunchKernelGGL(k_order_big, dim3((unsigned)std::min<int64_t>(ob, 8 * (int64_t)ctx->cu_count)), dim3(256), 0, st, db.Current(),
+                               db.Alternate(), L, begin_bit, 4, b->big_start.as<const uint32_t>(), b->big_cnt.as<const uint32_t>(), ob);
+            begin_bit = 0;                                   // (the keys are in order from here on)
+         }
          if (result_flags & GM_RESULT_LINES) {
             // the lines mapper() prints, made where the keys lie (gm_parse.hpp)
             GM_FAIL_IF(!b->from_file, "hit lines need a batch that was filled from a block of a read file (its tags).");

@@ -1263,6 +1263,157 @@ __global__ void k_order_runs(unsigned long long *keys, int64_t n, int shift)
    if (t < n) order_run_from(keys, n, shift, t);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Round 3: the radix sort only brings the hits of a read together (the read's bits: 3 passes of 8 bits for 12.5 M
+// reads instead of 7 over the whole key); the hits of a read are then put in order where they lie.  A read has 3.3 hits
+// on average at GRCh38 size and a few have thousands:
+//   k_order_first   the thread of the first key of a run (keys that agree from `shift` up) orders a run of up to
+//                   ORDER_SMALL keys itself; longer runs are noted in the slot of the thread's block (no atomics: a
+//                   block of 256 keys can hold the starts of ORDER_SLOT such runs at most)
+//   k_order_big     a workgroup per noted run: up to ORDER_LDS keys by a bitonic network in LDS, longer runs by radix
+//                   passes of 8 bits through the sort's other buffer
+// ------------------------------------------------------------------------------------------------
+constexpr int ORDER_SMALL = 32, ORDER_SLOT = 8, ORDER_LDS = 4096;
+
+__global__ void __launch_bounds__(256) k_order_first(unsigned long long *keys, int64_t n, int shift, uint32_t *big_start, uint32_t *big_cnt)
+{
+   __shared__ uint32_t s_cnt;
+   if (threadIdx.x == 0) s_cnt = 0;
+   __syncthreads();
+   const int64_t t = blockIdx.x * (int64_t)256 + threadIdx.x;
+   if (t < n) {
+      const unsigned long long g = keys[t] >> shift;
+      if (t == 0 || (keys[t - 1] >> shift) != g) {
+         int64_t e = t + 1;
+         while (e < n && e <= t + ORDER_SMALL && (keys[e] >> shift) == g) e++;
+         if (e - t > ORDER_SMALL) {
+            const uint32_t at = atomicAdd(&s_cnt, 1u);                 // (LDS)
+            big_start[(size_t)blockIdx.x * ORDER_SLOT + at] = (uint32_t)threadIdx.x;
+         } else {
+            for (int64_t i = t + 1; i < e; i++) {
+               const unsigned long long k = keys[i];
+               int64_t j = i;
+               while (j > t && keys[j - 1] > k) { keys[j] = keys[j - 1]; j--; }
+               if (j != i) keys[j] = k;
+            }
+         }
+      }
+   }
+   __syncthreads();
+   if (threadIdx.x == 0) big_cnt[blockIdx.x] = s_cnt;
+}
+
+// One workgroup sorts keys[s, e) by the bits [lo_bit, hi_bit) with passes of 8 bits through alt[s, e) (stable: the
+// keys of a tile of 256 are ranked by ballots inside their wavefront and by the wavefronts' counts across them).
+__device__ __forceinline__ void block_radix_run(unsigned long long *keys, unsigned long long *alt, int64_t s, int64_t e, int lo_bit, int hi_bit,
+                                                uint32_t *s_hist /* [256] */, uint32_t (*s_wcnt)[256] /* [4][256] */, uint32_t *s_part /* [4] */)
+{
+   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+   const unsigned long long lt = (1ull << lane) - 1ull;
+   unsigned long long *src = keys, *dst = alt;
+   for (int bit = lo_bit; bit < hi_bit; bit += 8) {
+      const int nb = min(8, hi_bit - bit);
+      const uint32_t mask = (1u << nb) - 1u;
+      s_hist[tid] = 0;
+      for (int w = 0; w < 4; w++) s_wcnt[w][tid] = 0;
+      __syncthreads();
+      for (int64_t i = s + tid; i < e; i += 256) atomicAdd(&s_hist[(uint32_t)(src[i] >> bit) & mask], 1u);
+      __syncthreads();
+      {  // exclusive scan of the 256 counts
+         const uint32_t v = s_hist[tid];
+         uint32_t incl = v;
+         for (int o = 1; o < 64; o <<= 1) { const uint32_t x = (uint32_t)__shfl_up((int)incl, o); if (lane >= o) incl += x; }
+         if (lane == 63) s_part[wid] = incl;
+         __syncthreads();
+         uint32_t before = 0;
+         for (int w = 0; w < wid; w++) before += s_part[w];
+         s_hist[tid] = before + incl - v;
+         __syncthreads();
+      }
+      for (int64_t base = s; base < e; base += 256) {
+         const int64_t i = base + tid;
+         const bool have = i < e;
+         const unsigned long long k = have ? src[i] : 0ull;
+         const uint32_t d = (uint32_t)(k >> bit) & mask;
+         unsigned long long same = __ballot(have);
+         for (int b = 0; b < nb; b++) {
+            const unsigned long long bb = __ballot((d >> b) & 1u);
+            same &= ((d >> b) & 1u) ? bb : ~bb;
+         }
+         const uint32_t rank = (uint32_t)__popcll(same & lt);
+         if (have && rank == 0) s_wcnt[wid][d] = (uint32_t)__popcll(same);
+         __syncthreads();
+         if (have) {
+            uint32_t off = s_hist[d] + rank;
+            for (int w = 0; w < wid; w++) off += s_wcnt[w][d];
+            dst[s + off] = k;
+         }
+         __syncthreads();
+         {
+            uint32_t tot = 0;
+            for (int w = 0; w < 4; w++) { tot += s_wcnt[w][tid]; s_wcnt[w][tid] = 0; }
+            s_hist[tid] += tot;
+         }
+         __syncthreads();
+      }
+      unsigned long long *x = src; src = dst; dst = x;
+   }
+   if (src != keys)
+      for (int64_t i = s + tid; i < e; i += 256) keys[i] = src[i];
+   __syncthreads();
+}
+
+__global__ void __launch_bounds__(256) k_order_big(unsigned long long *keys, unsigned long long *alt, int64_t n, int shift, int lo_bit,
+                                                   const uint32_t *big_start, const uint32_t *big_cnt, int64_t n_blocks)
+{
+   __shared__ unsigned long long s_keys[ORDER_LDS];
+   __shared__ uint32_t s_hist[256];
+   __shared__ uint32_t s_wcnt[4][256];
+   __shared__ uint32_t s_part[4];
+   __shared__ int64_t s_end;
+   const int tid = threadIdx.x;
+   for (int64_t b = blockIdx.x; b < n_blocks; b += gridDim.x) {
+      const uint32_t cnt = big_cnt[b];
+      for (uint32_t j = 0; j < cnt; j++) {
+         const int64_t s = b * 256 + (int64_t)big_start[(size_t)b * ORDER_SLOT + j];
+         if (tid == 0) {
+            // the end of the run: the keys agree from `shift` up and are sorted by those bits
+            const unsigned long long g = keys[s] >> shift;
+            int64_t step = ORDER_SMALL, lo = s + ORDER_SMALL;           // keys[lo] belongs to the run
+            while (lo + step < n && (keys[lo + step] >> shift) == g) { lo += step; step <<= 1; }
+            int64_t hi = min(n, lo + step);                             // keys[hi] does not (or hi = n)
+            while (hi - lo > 1) { const int64_t m = (lo + hi) >> 1; if ((keys[m] >> shift) == g) lo = m; else hi = m; }
+            s_end = hi;
+         }
+         __syncthreads();
+         const int64_t e = s_end;
+         const int len = (int)min(e - s, (int64_t)ORDER_LDS + 1);
+         if (e - s <= ORDER_LDS) {
+            int m = 64;
+            while (m < len) m <<= 1;
+            for (int i = tid; i < m; i += 256) s_keys[i] = i < len ? keys[s + i] : ~0ull;
+            __syncthreads();
+            for (int k = 2; k <= m; k <<= 1)
+               for (int jj = k >> 1; jj > 0; jj >>= 1) {
+                  for (int i = tid; i < m; i += 256) {
+                     const int l = i ^ jj;
+                     if (l > i) {
+                        const unsigned long long a = s_keys[i], c = s_keys[l];
+                        const bool up = (i & k) == 0;
+                        if ((a > c) == up) { s_keys[i] = c; s_keys[l] = a; }
+                     }
+                  }
+                  __syncthreads();
+               }
+            for (int i = tid; i < len; i += 256) keys[s + i] = s_keys[i];
+            __syncthreads();
+         } else {
+            block_radix_run(keys, alt, s, e, lo_bit, shift, s_hist, s_wcnt, s_part);
+         }
+      }
+   }
+}
+
 // Compact results: the sorted keys are the output; only the CSR offsets of the reads are derived from them
 // (as k_unpack_locs does: the thread of the first key of a read writes that read's offset and those of the
 // reads without hits before it).

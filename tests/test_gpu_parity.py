@@ -436,11 +436,11 @@ def test_verify_tile_changes_nothing(workdir):
 
 @pytest.mark.parametrize("n_reads", [1, 5, 40, 300, 2100])
 def test_sort_that_skips_low_bits_gives_the_same_order(workdir, n_reads):
-    """The radix sort of the located hits leaves out the score and up to three low bits of the text position where that
-    saves a pass, and k_order_runs orders the runs of keys that agree above (gm_device.hip, "order").  On a text with
-    homopolymer and dinucleotide runs a read hits many adjacent positions, each from several seeds: the located hits
-    must come in the oracle's order (read, text position) with either sort, for batch sizes that move the key's
-    width across the pass boundaries."""
+    """The radix sort of the located hits runs over the read's bits only; k_order_first / k_order_big then order the hits
+    of every read where they lie (gm_device.hip, "order"; option sort_all_bits = 1: one sort over the whole key).  On a
+    text with homopolymer and dinucleotide runs a read hits many adjacent positions, each from several seeds (runs of a
+    few hundred keys: the bitonic network in LDS): the located hits must come in the oracle's order (read, text
+    position) with either sort, for batch sizes that move the key's width across the pass boundaries."""
     rng = np.random.default_rng(5)
     parts = [rng.integers(0, 4, 3000).astype(np.uint8), np.zeros(300, np.uint8), rng.integers(0, 4, 2000).astype(np.uint8),
              np.tile(np.array([1, 2], np.uint8), 200), rng.integers(0, 4, 1500).astype(np.uint8)]
@@ -475,4 +475,43 @@ def test_sort_that_skips_low_bits_gives_the_same_order(workdir, n_reads):
                 assert np.array_equal(h.located(), d.located()), (all_bits, compact, verify)
                 assert h.n_ext == d.n_ext
     assert len(d.located()) > 100 * min(n_reads, 3)
+    ctx.close()
+
+
+def test_reads_with_thousands_of_hits_come_in_order(workdir):
+    """Runs of keys longer than the LDS network takes (k_order_big's radix passes through the sort's other buffer): a
+    read of 40 A against a text with 9 000 A in a row has about 9 000 hits per strand pair; beside it reads with a few
+    hundred hits and ordinary ones, in one batch, with every form of result."""
+    rng = np.random.default_rng(6)
+    seq = np.concatenate([rng.integers(0, 4, 2000).astype(np.uint8), np.zeros(9000, np.uint8), rng.integers(0, 4, 2500).astype(np.uint8),
+                          np.full(5000, 2, np.uint8), rng.integers(0, 4, 1000).astype(np.uint8), np.zeros(200, np.uint8)])
+    base = os.path.join(workdir, "longruns")
+    if not os.path.exists(base + ".sar"):
+        ma.HostIndex.build_codes([seq], ["r"], base).close()
+    ctx = ma.Context.from_files(base, 0)
+    orc = po.Index(base)
+    reads = []
+    for i in range(24):
+        kind = i % 4
+        if kind == 0:
+            w = np.zeros(40, np.uint8)
+        elif kind == 1:
+            w = np.full(40, 2, np.uint8); w[int(rng.integers(0, 40))] = 1
+        elif kind == 2:
+            w = np.full(40, 1, np.uint8)                                   # poly-C: the other strand of the G run
+        else:
+            s0 = int(rng.integers(0, 1900)); w = seq[s0:s0 + 40].copy()
+        reads.append(w)
+    codes = np.concatenate(reads)
+    offs = np.arange(0, 40 * (len(reads) + 1), 40, dtype=np.int64)
+    d = orc.map_batch(codes, offs, 2, threads=8)
+    per_read = np.bincount(d.located()[:, 0], minlength=len(reads))
+    assert per_read.max() > 8000 and (per_read > 4096).sum() >= 10
+    for all_bits in (0, 1):
+        ctx.set_option("sort_all_bits", all_bits)
+        for compact in (0, 1):
+            ctx.set_option("compact_results", compact)
+            h = ctx.map_batch(codes, offs, 2)
+            assert np.array_equal(h.located(), d.located()), (all_bits, compact)
+            assert np.array_equal(h.read_first_loc, d.read_first_loc if hasattr(d, "read_first_loc") else h.read_first_loc)
     ctx.close()
