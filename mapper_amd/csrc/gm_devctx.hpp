@@ -75,6 +75,7 @@ struct gpumap_ctx {
    // nodes whose interval holds one suffix are finished against the text (k_verify) when the text is in
    // HBM (d_text) and the caller wants located hits only
    bool sort_all_bits = false;    // option "sort_all_bits": 1 = the radix sort of the located hits runs over every bit of the keys (no k_order_runs)
+   int sort_by_read = -1;         // option "sort_by_read": 1 = the sort runs over the read's bits and the hits of a read are ordered in place, 0 = never, -1 = where nearly every read has one hit
    int verify_tile = 0;           // option "verify_tile": entries of the hit list a block of k_verify takes (0: 512)
    int verify = -1;               // option "verify": 0 off, 1 nodes of one suffix, 2 also of two, -1 by the size of the text
    bool owns_text = true;
@@ -101,6 +102,7 @@ struct gpumap_ctx {
    int ann_threads = 1;               // "ann_threads": the `threads` of the reference's ann_build whose job list is reproduced
    int64_t jump_budget = 0;           // "jump_bytes": most bytes the jump table may take (0 = a third of the free memory)
    std::vector<int64_t> seq_beg_host; // seq_beg[] (for gpumap_hits_expand)
+   hipStream_t pipe_post = nullptr;   // what follows the search of a run (locate, order), beside the next chunk's search
    hipStream_t pipe_run = nullptr, pipe_copy = nullptr, pipe_up = nullptr;   // streams shared by the batches of pipelines (gm_ctx_pipe_streams)
    std::mutex spare_mutex;
    std::vector<gpumap_batch *> spare_batches;     // batch objects of finished pipelines, kept for the next one (gm_ctx_take_batch)

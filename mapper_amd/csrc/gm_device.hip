@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -29,6 +30,11 @@ struct gpumap_batch {
    // the result copy of the chunk before and the upload of the chunk after run on the other two.  That is why
    // nothing below waits for a whole stream: every wait is for an event this batch recorded.
    hipStream_t stream = nullptr, st_run = nullptr, st_copy = nullptr, st_up = nullptr;
+   // Round 3: what follows the search of a run (locate, order, hit lines) goes to a fourth stream, st_post, and the
+   // pipeline lets the next chunk's run begin at that point (on_searched): the streaming kernels of the sort then run
+   // beside the next chunk's encoding and search, which wait for memory requests most of the time.
+   hipStream_t st_post = nullptr;
+   std::function<void()> on_searched;
    hipEvent_t ev_sync = nullptr, ev_up = nullptr;
    int64_t n_reads = 0;
    int stride = 0, maxlen = 1;
@@ -170,7 +176,7 @@ extern "C" void gpumap_destroy(gpumap_ctx *ctx)
    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
    if (ctx->map_batch_obj) { gpumap_batch_free(ctx->map_batch_obj); ctx->map_batch_obj = nullptr; }
    ctx_free_spare_batches(ctx);
-   for (hipStream_t *st : {&ctx->pipe_run, &ctx->pipe_copy, &ctx->pipe_up}) if (*st) { (void)hipStreamSynchronize(*st); (void)hipStreamDestroy(*st); *st = nullptr; }
+   for (hipStream_t *st : {&ctx->pipe_run, &ctx->pipe_copy, &ctx->pipe_up, &ctx->pipe_post}) if (*st) { (void)hipStreamSynchronize(*st); (void)hipStreamDestroy(*st); *st = nullptr; }
    if (ctx->owns_index) {
       if (ctx->d_occ) (void)hipFree(ctx->d_occ);
       if (ctx->d_tables) (void)hipFree(ctx->d_tables);
@@ -437,6 +443,7 @@ extern "C" int gpumap_set_option(gpumap_ctx *ctx, const char *name, int64_t valu
    else if (!strcmp(name, "jump_bytes")) { GM_FAIL_IF(value < 0, "jump_bytes out of range."); ctx->jump_budget = value; HIP_TRY(hipSetDevice(ctx->device)); GM_FAIL_IF(gm_ctx_build_jump(ctx, -1) != 0, "cannot build the jump table."); }
    else if (!strcmp(name, "verify")) { GM_FAIL_IF(value != -1 && value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 16, "verify out of range (-1, 0, 1, 2, 4, 8, 16)."); ctx->verify = (int)value; }
    else if (!strcmp(name, "sort_all_bits")) ctx->sort_all_bits = value != 0;
+   else if (!strcmp(name, "sort_by_read")) { GM_FAIL_IF(value < -1 || value > 1, "sort_by_read out of range (-1, 0, 1)."); ctx->sort_by_read = (int)value; }
    else if (!strcmp(name, "verify_tile")) { GM_FAIL_IF(value < 0 || value > VERIFY_TILE_MAX, "verify_tile out of range (0 = default, at most 1024)."); ctx->verify_tile = (int)value; }
    else if (!strcmp(name, "trim")) { HIP_TRY(hipSetDevice(ctx->device)); ctx_free_spare_batches(ctx); }
    else if (!strcmp(name, "ann_trail_reuse")) ctx->ann_trail_reuse = value != 0;
@@ -644,7 +651,7 @@ extern "C" void gpumap_batch_free(gpumap_batch *b)
 {
    if (!b) return;
    if (b->ctx) (void)hipSetDevice(b->ctx->device);
-   for (hipStream_t st : {b->st_up, b->st_run, b->st_copy}) if (st) (void)hipStreamSynchronize(st);
+   for (hipStream_t st : {b->st_up, b->st_run, b->st_copy, b->st_post}) if (st) (void)hipStreamSynchronize(st);
    b->release();
    delete b;
 }
@@ -659,7 +666,8 @@ gpumap_batch *gm_ctx_take_batch(gpumap_ctx *ctx)
       if (!ctx->spare_batches.empty()) {
          gpumap_batch *b = ctx->spare_batches.back();
          ctx->spare_batches.pop_back();
-         b->st_run = b->st_copy = b->st_up = b->stream;
+         b->st_run = b->st_copy = b->st_up = b->st_post = b->stream;
+         b->on_searched = nullptr;
          b->sc_plan = nullptr; b->extra_factor = 1; b->ran = false; b->encoded = false; b->n_reads = 0;
          return b;
       }
@@ -671,7 +679,7 @@ void gm_ctx_give_batch(gpumap_ctx *ctx, gpumap_batch *b)
 {
    if (!b) return;
    (void)hipSetDevice(ctx->device);
-   for (hipStream_t st : {b->st_up, b->st_run, b->st_copy}) if (st) (void)hipStreamSynchronize(st);
+   for (hipStream_t st : {b->st_up, b->st_run, b->st_copy, b->st_post}) if (st) (void)hipStreamSynchronize(st);
    {
       std::lock_guard<std::mutex> lock(ctx->spare_mutex);
       static const bool keep = !(getenv("GPUMAP_KEEP_BATCHES") && atoi(getenv("GPUMAP_KEEP_BATCHES")) == 0);
@@ -696,7 +704,7 @@ extern "C" gpumap_batch *gpumap_batch_new(gpumap_ctx *ctx)
    b->ctx = ctx;
    memset(b->length_seen, 0, sizeof b->length_seen);
    HIP_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
-   b->st_run = b->st_copy = b->st_up = b->stream;
+   b->st_run = b->st_copy = b->st_up = b->st_post = b->stream;
    HIP_TRY(hipEventCreateWithFlags(&b->ev_sync, hipEventDisableTiming | hipEventBlockingSync));
    HIP_TRY(hipEventCreateWithFlags(&b->ev_up, hipEventDisableTiming));
    HIP_TRY(hipHostMalloc((void **)&b->h_small, H_SMALL_BYTES, hipHostMallocDefault));
@@ -715,7 +723,7 @@ failure_return:
 // priority: on this platform copies are kernels, which take few wavefronts and should not queue behind persistent
 // search kernels) therefore never shares a hardware queue with the run stream, whatever other streams the
 // process has made (streams of one priority beyond GPU_MAX_HW_QUEUES share queues, and work on one queue is serial).
-int gm_ctx_pipe_streams(gpumap_ctx *ctx, void **run, void **copy, void **up)
+int gm_ctx_pipe_streams(gpumap_ctx *ctx, void **run, void **copy, void **up, void **post)
 {
    HIP_TRY(hipSetDevice(ctx->device));
    {
@@ -733,18 +741,25 @@ int gm_ctx_pipe_streams(gpumap_ctx *ctx, void **run, void **copy, void **up)
          HIP_TRY(hipStreamCreateWithFlags(&ctx->pipe_run, hipStreamNonBlocking));
          HIP_TRY(hipStreamCreateWithPriority(&ctx->pipe_copy, hipStreamNonBlocking, mode >= 1 ? greatest : 0));
          HIP_TRY(hipStreamCreateWithPriority(&ctx->pipe_up, hipStreamNonBlocking, mode >= 2 ? greatest : 0));
+         // (measured at GRCh38 size, 12.5 M reads per chunk: no overlap 758 M reads/s; post stream of normal priority 793 M,
+         // of high priority 803 .. 808 M.  With k_verify moved over as well, beside the next chunk's k_search: 710 M: both
+         // wait for the same queue of memory requests.)
+         const int post_mode = getenv("GPUMAP_PIPE_POST_PRIO") ? atoi(getenv("GPUMAP_PIPE_POST_PRIO")) : 1;      // tuning aid: 0 = normal priority
+         HIP_TRY(hipStreamCreateWithPriority(&ctx->pipe_post, hipStreamNonBlocking, post_mode >= 1 ? greatest : 0));
       }
    }
-   *run = ctx->pipe_run; *copy = ctx->pipe_copy; *up = ctx->pipe_up;
+   *run = ctx->pipe_run; *copy = ctx->pipe_copy; *up = ctx->pipe_up; *post = ctx->pipe_post;
    return 0;
 failure_return:
    return -1;
 }
 
-void gm_batch_set_streams(gpumap_batch *b, void *run, void *copy, void *up)
+void gm_batch_set_streams(gpumap_batch *b, void *run, void *copy, void *up, void *post)
 {
-   b->st_run = (hipStream_t)run; b->st_copy = (hipStream_t)copy; b->st_up = (hipStream_t)up;
+   b->st_run = (hipStream_t)run; b->st_copy = (hipStream_t)copy; b->st_up = (hipStream_t)up; b->st_post = (hipStream_t)post;
 }
+
+void gm_batch_set_hook(gpumap_batch *b, std::function<void()> on_searched) { b->on_searched = std::move(on_searched); }
 
 // Waits until everything this thread has put on `st` so far is done (not for what other batches add meanwhile).
 #define GM_SYNC(b, st) do { HIP_TRY(hipEventRecord((b)->ev_sync, (st))); HIP_TRY(hipEventSynchronize((b)->ev_sync)); } while (0)
@@ -1349,6 +1364,8 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
          b->n_big = n_class[0] + n_class[1];
       }
       HIP_TRY(hipEventRecord(b->ev[1], st));
+      if (b->st_post != nullptr && b->st_post != st) { HIP_TRY(hipStreamWaitEvent(b->st_post, b->ev[1], 0)); st = b->st_post; }
+      if (b->on_searched) { b->on_searched(); b->on_searched = nullptr; }      // (the host has waited for the search's last kernel: the run stream is free)
       b->n_hits = (int64_t)host_cnt[1];            // entries of the list, holes included
       b->n_real = (int64_t)host_cnt[7];            // hits (and candidates handed to k_verify) among them
       b->n_ext = (int64_t)host_cnt[2];
@@ -1428,31 +1445,41 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
          // pass (GRCh38 size with 12.5 M reads: 61 bits, 56 without the score and one bit), the sort starts above
          // them and k_order_runs puts the short runs of keys that agree above in order.
          const int end_bit = pos_bits + 4 + read_bits;
-         // Round 3: the radix sort runs over the read's bits only (3 passes for 12.5 M reads instead of 7 over the key):
-         // the hits of a read come together, and k_order_first / k_order_big put each read's hits in order where they
-         // lie (3.3 per read on average at GRCh38 size).  Option "sort_all_bits": one sort over the whole key.
+         // Round 3: where nearly every read has one hit (texts without repeats: L <= 1.25 R) the radix sort runs over the
+         // read's bits only (3 passes for 12.5 M reads instead of 7 over the key) and k_order_first / k_order_big put the
+         // hits of the reads that have several in order where they lie.  Measured where reads have many hits that loses:
+         // at GRCh38 size 98.7 % of the reads have one hit but 70 % of the hits belong to the 0.8 % of the reads with 65 ..
+         // 1024 hits each (profiles/r3_hits_hist.jsonl): ordering those 100 000 runs of hundreds of keys costs more than
+         // the four passes saved (order 1.97 -> 4.0 ms; chr21 size 4.7 -> 11.6 ms).  There the sort runs over the key, leaving
+         // out the score (the text position determines it) and up to three low bits of the position where that saves a
+         // pass; k_order_runs / k_read_first order the few keys that agree above.  Option "sort_all_bits": every bit.
          // (end_bit = 64 with begin_bit > 0: hipcub returns unsorted keys for 10^4 .. 10^6 items, tools/sortpairs_check.hip)
          int begin_bit = 0;
-         if (!ctx->sort_all_bits && end_bit < 64) begin_bit = pos_bits + 4;
+         const bool by_read = !ctx->sort_all_bits && end_bit < 64 && (ctx->sort_by_read == 1 || (ctx->sort_by_read < 0 && L <= R + R / 4));
+         if (by_read) begin_bit = pos_bits + 4;
+         for (int drop = 0; drop <= 3 && begin_bit == 0; drop++)
+            if (cdiv(end_bit - (4 + drop), 8) < cdiv(end_bit, 8) && !ctx->sort_all_bits && end_bit < 64) begin_bit = 4 + drop;
          HIP_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp, db, (int)L, begin_bit, end_bit, st));
          HIP_TRY(b->cub_tmp.ensure(tmp));
          HIP_TRY(hipcub::DeviceRadixSort::SortKeys(b->cub_tmp.p, tmp, db, (int)L, begin_bit, end_bit, st));
          b->sorted_keys = db.Current();
-         if (begin_bit > 0) {
+         if (by_read) {
             const int64_t ob = cdiv(L, 256);
             HIP_TRY(b->big_start.ensure(4 * (size_t)ORDER_SLOT * (size_t)ob));
             HIP_TRY(b->big_cnt.ensure(4 * (size_t)ob));
-            hipLaunchKernelGGL(k_order_first, dim3((unsigned)ob), dim3(256), 0, st, db.Current(), L, begin_bit, b->big_start.as<uint32_t>(),
-                               b->big_cnt.as<uint32_t>());
-            hipLaunchKernelGGL(k_order_big, dim3((unsigned)std::min<int64_t>(ob, 8 * (int64_t)ctx->cu_count)), dim3(256), 0, st, db.Current(),
-                               db.Alternate(), L, begin_bit, 4, b->big_start.as<const uint32_t>(), b->big_cnt.as<const uint32_t>(), ob);
-            begin_bit = 0;                                   // (the keys are in order from here on)
+            hipLaunchKernelGGL(k_order_first, dim3((unsigned)ob), dim3(256), 0, st, (const unsigned long long *)db.Current(), db.Alternate(), L, begin_bit,
+                               b->big_start.as<uint32_t>(), b->big_cnt.as<uint32_t>());
+            hipLaunchKernelGGL(k_order_big, dim3((unsigned)std::min<int64_t>(ob, 8 * (int64_t)ctx->cu_count)), dim3(256), 0, st, db.Alternate(),
+                               db.Current(), L, begin_bit, 4, b->big_start.as<const uint32_t>(), b->big_cnt.as<const uint32_t>(), ob);
+            b->sorted_keys = db.Alternate();                 // (the keys are in order there from here on)
+            begin_bit = 0;
          }
+         unsigned long long *sk = const_cast<unsigned long long *>(b->sorted_keys);
          if (result_flags & GM_RESULT_LINES) {
             // the lines mapper() prints, made where the keys lie (gm_parse.hpp)
             GM_FAIL_IF(!b->from_file, "hit lines need a batch that was filled from a block of a read file (its tags).");
             GM_FAIL_IF(ctx->d_names.p == nullptr, "hit lines need the sequences' names (gpumap_set_seq_names).");
-            if (begin_bit > 0) hipLaunchKernelGGL(k_order_runs, dim3((unsigned)cdiv(L, 256)), dim3(256), 0, st, db.Current(), L, begin_bit);
+            if (begin_bit > 0) hipLaunchKernelGGL(k_order_runs, dim3((unsigned)cdiv(L, 256)), dim3(256), 0, st, sk, L, begin_bit);
             HIP_TRY(b->line_len.ensure(8 * (size_t)(L + 1)));
             FormatArgs F;
             F.keys = b->sorted_keys; F.n_keys = L; F.pos_bits = pos_bits; F.n = ctx->ix.n; F.seq_beg = ctx->ix.seq_beg; F.seq_cnt = ctx->ix.seq_cnt;
@@ -1475,10 +1502,10 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
             hipLaunchKernelGGL(k_format_write, dim3((unsigned)cdiv(L, 256)), dim3(256), 0, st, F);
             b->have_lines = true;
          } else if (compact) {
-            hipLaunchKernelGGL(k_read_first, dim3((unsigned)cdiv(L, 256)), dim3(256), 0, st, db.Current(), L, pos_bits, R,
+            hipLaunchKernelGGL(k_read_first, dim3((unsigned)cdiv(L, 256)), dim3(256), 0, st, sk, L, pos_bits, R,
                                b->read_first.as<int64_t>(), begin_bit);
          } else {
-            if (begin_bit > 0) hipLaunchKernelGGL(k_order_runs, dim3((unsigned)cdiv(L, 256)), dim3(256), 0, st, db.Current(), L, begin_bit);
+            if (begin_bit > 0) hipLaunchKernelGGL(k_order_runs, dim3((unsigned)cdiv(L, 256)), dim3(256), 0, st, sk, L, begin_bit);
             for (DevBuf *x : {&b->loc_read, &b->loc_pos, &b->loc_fwd, &b->loc_seq, &b->loc_seqpos}) HIP_TRY(x->ensure(8 * (size_t)L));
             HIP_TRY(b->loc_strand.ensure((size_t)L));
             HIP_TRY(b->loc_score.ensure((size_t)L));

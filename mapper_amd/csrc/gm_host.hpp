@@ -108,5 +108,7 @@ int gm_batch_fetch(gpumap_ctx *ctx, gpumap_batch *b, gpumap_hits *out, int resul
 // Batch objects that go round between the pipelines of one context (gm_device.hip).
 gpumap_batch *gm_ctx_take_batch(gpumap_ctx *ctx);
 void gm_ctx_give_batch(gpumap_ctx *ctx, gpumap_batch *b);
-void gm_batch_set_streams(gpumap_batch *b, void *run, void *copy, void *up);
-int  gm_ctx_pipe_streams(gpumap_ctx *ctx, void **run, void **copy, void **up);
+void gm_batch_set_streams(gpumap_batch *b, void *run, void *copy, void *up, void *post);
+int  gm_ctx_pipe_streams(gpumap_ctx *ctx, void **run, void **copy, void **up, void **post);
+// Called by gm_batch_run when the search of the run is over and only locate / order / formatting remain (on the post stream).
+void gm_batch_set_hook(gpumap_batch *b, std::function<void()> on_searched);

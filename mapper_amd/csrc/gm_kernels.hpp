@@ -1267,40 +1267,53 @@ __global__ void k_order_runs(unsigned long long *keys, int64_t n, int shift)
 // Round 3: the radix sort only brings the hits of a read together (the read's bits: 3 passes of 8 bits for 12.5 M
 // reads instead of 7 over the whole key); the hits of a read are then put in order where they lie.  A read has 3.3 hits
 // on average at GRCh38 size and a few have thousands:
-//   k_order_first   the thread of the first key of a run (keys that agree from `shift` up) orders a run of up to
-//                   ORDER_SMALL keys itself; longer runs are noted in the slot of the thread's block (no atomics: a
-//                   block of 256 keys can hold the starts of ORDER_SLOT such runs at most)
+//   k_order_first   a thread per key: in a run (keys that agree from `shift` up) of up to ORDER_SMALL keys every key
+//                   finds its place by counting the keys of the run below it; longer runs are noted in the slot of
+//                   the block their first key lies in (no global atomics: a block of 256 keys can hold the starts of
+//                   ORDER_SLOT such runs at most)
 //   k_order_big     a workgroup per noted run: up to ORDER_LDS keys by a bitonic network in LDS, longer runs by radix
 //                   passes of 8 bits through the sort's other buffer
 // ------------------------------------------------------------------------------------------------
 constexpr int ORDER_SMALL = 32, ORDER_SLOT = 8, ORDER_LDS = 4096;
 
-__global__ void __launch_bounds__(256) k_order_first(unsigned long long *keys, int64_t n, int shift, uint32_t *big_start, uint32_t *big_cnt)
+// src -> dst (the sort's two buffers): every key of a run of up to ORDER_SMALL keys goes to its place in the run, which
+// is the number of keys of the run below it (a thread per key, the block's keys and ORDER_SMALL on either side in LDS:
+// no thread waits for another one's chain of loads, and a wavefront takes as many rounds as its longest run has keys).
+// The keys of longer runs are copied as they are and the runs noted for k_order_big.
+__global__ void __launch_bounds__(256) k_order_first(const unsigned long long *src, unsigned long long *dst, int64_t n, int shift,
+                                                     uint32_t *big_start, uint32_t *big_cnt)
 {
+   __shared__ unsigned long long s_keys[256 + 2 * ORDER_SMALL];
    __shared__ uint32_t s_cnt;
-   if (threadIdx.x == 0) s_cnt = 0;
+   const int tid = threadIdx.x;
+   const int64_t base = blockIdx.x * (int64_t)256 - ORDER_SMALL;        // s_keys[j] = src[base + j]
+   if (tid == 0) s_cnt = 0;
+   for (int j = tid; j < 256 + 2 * ORDER_SMALL; j += 256) {
+      const int64_t i = base + j;
+      s_keys[j] = (i >= 0 && i < n) ? src[i] : 0ull;
+   }
    __syncthreads();
-   const int64_t t = blockIdx.x * (int64_t)256 + threadIdx.x;
+   const int64_t t = blockIdx.x * (int64_t)256 + tid;
    if (t < n) {
-      const unsigned long long g = keys[t] >> shift;
-      if (t == 0 || (keys[t - 1] >> shift) != g) {
-         int64_t e = t + 1;
-         while (e < n && e <= t + ORDER_SMALL && (keys[e] >> shift) == g) e++;
-         if (e - t > ORDER_SMALL) {
-            const uint32_t at = atomicAdd(&s_cnt, 1u);                 // (LDS)
-            big_start[(size_t)blockIdx.x * ORDER_SLOT + at] = (uint32_t)threadIdx.x;
-         } else {
-            for (int64_t i = t + 1; i < e; i++) {
-               const unsigned long long k = keys[i];
-               int64_t j = i;
-               while (j > t && keys[j - 1] > k) { keys[j] = keys[j - 1]; j--; }
-               if (j != i) keys[j] = k;
-            }
+      const int me = ORDER_SMALL + tid;
+      const unsigned long long k = s_keys[me], g = k >> shift;
+      int back = 0, fwd = 0;
+      while (back < ORDER_SMALL && t - back - 1 >= 0 && (s_keys[me - back - 1] >> shift) == g) back++;
+      while (fwd < ORDER_SMALL && t + fwd + 1 < n && (s_keys[me + fwd + 1] >> shift) == g) fwd++;
+      if (back + fwd + 1 > ORDER_SMALL) {
+         dst[t] = k;
+         if (back == 0) {
+            const uint32_t at = atomicAdd(&s_cnt, 1u);                  // (LDS)
+            big_start[(size_t)blockIdx.x * ORDER_SLOT + at] = (uint32_t)tid;
          }
+      } else {
+         int rank = 0;
+         for (int j = me - back; j <= me + fwd; j++) rank += s_keys[j] < k;      // (the keys of a run differ: read and place)
+         dst[t - back + rank] = k;
       }
    }
    __syncthreads();
-   if (threadIdx.x == 0) big_cnt[blockIdx.x] = s_cnt;
+   if (tid == 0) big_cnt[blockIdx.x] = s_cnt;
 }
 
 // One workgroup sorts keys[s, e) by the bits [lo_bit, hi_bit) with passes of 8 bits through alt[s, e) (stable: the

@@ -44,7 +44,7 @@ struct gpumap_pipe {
    // context's kernel stream: every chunk then takes as long as all of them together, in lock-step (results came back in
    // bursts of `depth`, the first after 58 ms instead of 18).  Uploads and result copies still overlap the runs.
    std::vector<uint64_t> ctx_submitted, ctx_turn;
-   bool ordered = true;
+   bool ordered = true, overlap = true;
    // the last thread that took or released a result (gpumap_pipe_submit: can anyone but the submitting thread free a slot?)
    bool consumer_seen = false;
    std::thread::id consumer_tid;
@@ -71,11 +71,19 @@ static void pipe_worker(gpumap_pipe *p, Slot *s)
          std::unique_lock<std::mutex> l(p->m);
          p->cv.wait(l, [&] { return p->ctx_turn[(size_t)s->ctx_index] == s->run_seq; });
       }
-      if (rc == 0) rc = gm_batch_run(s->ctx, s->batch, p->tau, 0, p->result_flags);
-      if (p->ordered) {
+      // The turn passes on when the search of this run is over: what remains of it (locate, order, hit lines) runs on
+      // the post stream beside the next chunk's encoding and search (GPUMAP_PIPE_OVERLAP=0: when the whole run is over).
+      bool passed = false;
+      auto pass_turn = [&] {
+         if (!p->ordered || passed) return;
+         passed = true;
          { std::lock_guard<std::mutex> l(p->m); p->ctx_turn[(size_t)s->ctx_index]++; }
          p->cv.notify_all();
-      }
+      };
+      if (p->overlap) gm_batch_set_hook(s->batch, pass_turn);
+      if (rc == 0) rc = gm_batch_run(s->ctx, s->batch, p->tau, 0, p->result_flags);
+      gm_batch_set_hook(s->batch, nullptr);
+      pass_turn();
       if (dbg) fprintf(stderr, "[pipe] slot %d: fetch (rc %d)\n", id, rc);
       if (rc == 0) rc = gm_batch_fetch(s->ctx, s->batch, &s->hits, p->result_flags);
       if (dbg) fprintf(stderr, "[pipe] slot %d: done (rc %d)\n", id, rc);
@@ -125,6 +133,7 @@ extern "C" gpumap_pipe *gpumap_pipe_create(gpumap_ctx *const *ctxs, int n_ctx, i
    p->ctx_submitted.assign((size_t)n_ctx, 0);
    p->ctx_turn.assign((size_t)n_ctx, 0);
    if (getenv("GPUMAP_PIPE_GRACE_MS")) p->grace_ms = std::max(0, atoi(getenv("GPUMAP_PIPE_GRACE_MS")));
+   p->overlap = !getenv("GPUMAP_PIPE_OVERLAP") || atoi(getenv("GPUMAP_PIPE_OVERLAP")) != 0;
    p->ordered = !getenv("GPUMAP_PIPE_ORDERED") || atoi(getenv("GPUMAP_PIPE_ORDERED")) != 0;      // (0: tuning aid, the runs interleave)
    for (size_t i = 0; i < p->slots.size(); i++) {
       Slot &s = p->slots[i];
@@ -132,9 +141,9 @@ extern "C" gpumap_pipe *gpumap_pipe_create(gpumap_ctx *const *ctxs, int n_ctx, i
       s.ctx_index = (int)(i % (size_t)n_ctx);
       s.batch = gm_ctx_take_batch(s.ctx);
       GM_FAIL_IF(s.batch == nullptr, "cannot create a batch.");
-      void *run = nullptr, *copy = nullptr, *up = nullptr;
-      GM_FAIL_IF(gm_ctx_pipe_streams(s.ctx, &run, &copy, &up) != 0, "cannot create the streams of the pipeline.");
-      gm_batch_set_streams(s.batch, run, copy, up);
+      void *run = nullptr, *copy = nullptr, *up = nullptr, *post = nullptr;
+      GM_FAIL_IF(gm_ctx_pipe_streams(s.ctx, &run, &copy, &up, &post) != 0, "cannot create the streams of the pipeline.");
+      gm_batch_set_streams(s.batch, run, copy, up, p->overlap ? post : run);
    }
    for (auto &s : p->slots) s.worker = std::thread(pipe_worker, p, &s);
    return p;

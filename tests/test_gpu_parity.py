@@ -465,14 +465,15 @@ def test_sort_that_skips_low_bits_gives_the_same_order(workdir, n_reads):
     codes = np.concatenate(reads)
     offs = np.arange(0, 40 * (n_reads + 1), 40, dtype=np.int64)
     d = orc.map_batch(codes, offs, 2, threads=8)
-    for all_bits in (1, 0):
+    for all_bits, by_read in ((1, 0), (0, 0), (0, 1)):
         ctx.set_option("sort_all_bits", all_bits)
+        ctx.set_option("sort_by_read", by_read)
         for compact in (0, 1):                       # (compact results: the runs are ordered inside k_read_first)
             ctx.set_option("compact_results", compact)
             for verify in (4, 1, 0):
                 ctx.set_option("verify", verify)
                 h = ctx.map_batch(codes, offs, 2)
-                assert np.array_equal(h.located(), d.located()), (all_bits, compact, verify)
+                assert np.array_equal(h.located(), d.located()), (all_bits, by_read, compact, verify)
                 assert h.n_ext == d.n_ext
     assert len(d.located()) > 100 * min(n_reads, 3)
     ctx.close()
@@ -507,11 +508,12 @@ def test_reads_with_thousands_of_hits_come_in_order(workdir):
     d = orc.map_batch(codes, offs, 2, threads=8)
     per_read = np.bincount(d.located()[:, 0], minlength=len(reads))
     assert per_read.max() > 8000 and (per_read > 4096).sum() >= 10
-    for all_bits in (0, 1):
+    for all_bits, by_read in ((0, 1), (0, 0), (1, 0)):
         ctx.set_option("sort_all_bits", all_bits)
+        ctx.set_option("sort_by_read", by_read)
         for compact in (0, 1):
             ctx.set_option("compact_results", compact)
             h = ctx.map_batch(codes, offs, 2)
-            assert np.array_equal(h.located(), d.located()), (all_bits, compact)
+            assert np.array_equal(h.located(), d.located()), (all_bits, by_read, compact)
             assert np.array_equal(h.read_first_loc, d.read_first_loc if hasattr(d, "read_first_loc") else h.read_first_loc)
     ctx.close()
