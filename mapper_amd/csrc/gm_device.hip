@@ -1364,7 +1364,10 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
          b->n_big = n_class[0] + n_class[1];
       }
       HIP_TRY(hipEventRecord(b->ev[1], st));
-      if (b->st_post != nullptr && b->st_post != st) { HIP_TRY(hipStreamWaitEvent(b->st_post, b->ev[1], 0)); st = b->st_post; }
+      // (the post stream has a higher priority than the run stream: it must not wait ON THE DEVICE for an event of the run
+      // stream: with chunks of a few reads that stalled both for good, as the low-priority upload stream of round 2 did;
+      // the host waits for the run stream instead, which is idle or nearly so at this point)
+      if (b->st_post != nullptr && b->st_post != st) { GM_SYNC(b, st); st = b->st_post; }
       if (b->on_searched) { b->on_searched(); b->on_searched = nullptr; }      // (the host has waited for the search's last kernel: the run stream is free)
       b->n_hits = (int64_t)host_cnt[1];            // entries of the list, holes included
       b->n_real = (int64_t)host_cnt[7];            // hits (and candidates handed to k_verify) among them

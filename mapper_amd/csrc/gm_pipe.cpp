@@ -64,9 +64,10 @@ static void pipe_worker(gpumap_pipe *p, Slot *s)
       memset(&s->hits, 0, sizeof s->hits);
       static const bool dbg = getenv("GPUMAP_PIPE_DEBUG") != nullptr;
       const int id = (int)(s - p->slots.data());
-      if (dbg) fprintf(stderr, "[pipe] slot %d: fill %ld reads\n", id, (long)s->n_reads);
+      auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+      if (dbg) fprintf(stderr, "[pipe %.2f] slot %d: fill %ld reads\n", now_ms(), id, (long)s->n_reads);
       int rc = gm_batch_fill(s->ctx, s->batch, s->src, s->offsets, s->n_reads, p->src_flags, false);
-      if (dbg) fprintf(stderr, "[pipe] slot %d: run (rc %d)\n", id, rc);
+      if (dbg) fprintf(stderr, "[pipe %.2f] slot %d: run (rc %d)\n", now_ms(), id, rc);
       if (p->ordered) {
          std::unique_lock<std::mutex> l(p->m);
          p->cv.wait(l, [&] { return p->ctx_turn[(size_t)s->ctx_index] == s->run_seq; });
@@ -84,9 +85,9 @@ static void pipe_worker(gpumap_pipe *p, Slot *s)
       if (rc == 0) rc = gm_batch_run(s->ctx, s->batch, p->tau, 0, p->result_flags);
       gm_batch_set_hook(s->batch, nullptr);
       pass_turn();
-      if (dbg) fprintf(stderr, "[pipe] slot %d: fetch (rc %d)\n", id, rc);
+      if (dbg) fprintf(stderr, "[pipe %.2f] slot %d: fetch (rc %d)\n", now_ms(), id, rc);
       if (rc == 0) rc = gm_batch_fetch(s->ctx, s->batch, &s->hits, p->result_flags);
-      if (dbg) fprintf(stderr, "[pipe] slot %d: done (rc %d)\n", id, rc);
+      if (dbg) fprintf(stderr, "[pipe %.2f] slot %d: done (rc %d)\n", now_ms(), id, rc);
       {
          std::lock_guard<std::mutex> l(p->m);
          s->rc = rc;
