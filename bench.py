@@ -511,10 +511,12 @@ def pmc_traffic(workload):
     for rnd in ("r3", "r2", "r1"):
         path = os.path.join(ROOT, "profiles", "%s_%s_profile_summary.json" % (rnd, workload))
         try:
-            pm = json.load(open(path))["pmc_per_launch"]
+            doc = json.load(open(path))
+            pm = doc["pmc_per_launch"]
             k = next(v for name, v in pm.items() if "gm::k_search" in name)
             req = k.get("TCC_EA0_RDREQ_sum", {}).get("avg")
-            return (k["FETCH_SIZE"]["avg"] + k["WRITE_SIZE"]["avg"]) * 1024.0, os.path.relpath(path, ROOT), req
+            src = "%s (counters of the build at commit %s)" % (os.path.relpath(path, ROOT), doc.get("commit", "unknown"))
+            return (k["FETCH_SIZE"]["avg"] + k["WRITE_SIZE"]["avg"]) * 1024.0, src, req
         except Exception:
             continue
     return None, None, None
@@ -551,7 +553,7 @@ def pmc_verify_traffic(workload):
             for name, v in d["pmc_per_launch"].items():
                 if "gm::k_verify" in name:
                     by += (v["FETCH_SIZE"]["avg"] + v["WRITE_SIZE"]["avg"]) * 1024.0
-            for v in d["kernel_stats"]:
+            for v in d.get("kernel_stats_serial") or d["kernel_stats"]:
                 if "gm::k_verify" in v["kernel"]:
                     ms += v["avg_ns"] * 1e-6                      # (one launch of each instance per chunk)
             if by > 0 and ms > 0:

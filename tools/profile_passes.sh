@@ -3,7 +3,9 @@
 #   tools/profile_passes.sh OUTDIR WORKLOAD [extra bench args]
 # pass 0: --kernel-trace --stats; then one --pmc pass per counter group (never combined with traces).
 # Each pass is its own process with its own time limit; the script stops at the first failure.
-# PMC_ONLY="7 8" runs only the named counter passes (and no stats pass).
+# pass 0 runs twice: as the product runs (chunks overlap on the pipeline's streams) and with GPUMAP_PIPE_OVERLAP=0
+# (every launch alone on the device: the duration bench.py's HIP events measure).
+# PMC_ONLY="7 8" runs only the named counter passes (and no stats pass).  COMMIT=<id> is recorded in the summary.
 # Raw rocprofv3 output stays in /tmp (gpurun_out/ is limited to 64 MiB); summaries go to OUTDIR.
 out=$1; shift; wl=$1; shift
 R=$GRAFT_REPO_ROOT
@@ -14,6 +16,7 @@ cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --workload $wl --steps 2 --warmup 1 --no-cpu-baseline $*"
 if [ -z "$PMC_ONLY" ]; then
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $raw/stats -- $B > $raw/stats.json 2> $raw/stats.err || { echo "stats pass failed"; tail -5 $raw/stats.err; exit 1; }
+GPUMAP_PIPE_OVERLAP=0 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $raw/stats_serial -- $B > $raw/stats_serial.json 2> $raw/stats_serial.err || { echo "serial stats pass failed"; tail -5 $raw/stats_serial.err; exit 1; }
 fi
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" \
@@ -28,6 +31,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum
 done
 python3 $R/tools/profile_summary.py $raw > $final/summary.json || exit 1
 [ -z "$PMC_ONLY" ] && cp "$(ls -S $(find $raw/stats -name "*kernel_stats.csv") | head -1)" $final/kernel_stats.csv   # (the largest: the bench, not the gather microbenchmark it starts)
+[ -z "$PMC_ONLY" ] && cp "$(ls -S $(find $raw/stats_serial -name "*kernel_stats.csv") | head -1)" $final/kernel_stats_serial.csv
 cp $raw/*.json $final/ 2>/dev/null
 for d in $raw/pmc*/; do n=$(basename $d); head -1 $d/*/*counter_collection.csv > $final/$n.counters.csv; grep -E "k_search|k_verify|k_place|k_encode" $d/*/*counter_collection.csv >> $final/$n.counters.csv; done
 cat $final/summary.json

@@ -4,13 +4,19 @@ kernel-trace stats of our kernels and, per PMC counter, the average per launch o
 import csv, glob, json, os, sys
 
 def main(root):
-    out = {"kernel_stats": [], "pmc_per_launch": {}, "bench_lines": {}}
-    for f in glob.glob(os.path.join(root, "stats", "**", "*kernel_stats.csv"), recursive=True):
-        for r in csv.DictReader(open(f)):
-            name = r["Name"]
-            if "gm::" in name or "rocprim" in name or "rocclr" in name:
-                out["kernel_stats"].append({"kernel": name.split("(")[0][:90], "calls": int(r["Calls"]),
-                                            "avg_ns": float(r["AverageNs"]), "pct": float(r["Percentage"])})
+    out = {"commit": os.environ.get("COMMIT", "unknown"), "kernel_stats": [], "kernel_stats_serial": [],
+           "pmc_per_launch": {}, "bench_lines": {}}
+    # "stats": the product configuration (chunks of the pipeline overlap on four streams, so a kernel's launches beside
+    # another chunk's ordering take longer); "stats_serial": GPUMAP_PIPE_OVERLAP=0, every launch alone on the device,
+    # the figure the HIP events of bench.py's roofline measure.
+    for sub, key in (("stats", "kernel_stats"), ("stats_serial", "kernel_stats_serial")):
+        for f in glob.glob(os.path.join(root, sub, "**", "*kernel_stats.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                name = r["Name"]
+                if "gm::" in name or "rocprim" in name or "rocclr" in name:
+                    out[key].append({"kernel": name.split("(")[0][:90], "calls": int(r["Calls"]),
+                                     "avg_ns": float(r["AverageNs"]), "min_ns": float(r["MinNs"]),
+                                     "max_ns": float(r["MaxNs"]), "pct": float(r["Percentage"])})
     for f in sorted(glob.glob(os.path.join(root, "pmc*", "**", "*counter_collection.csv"), recursive=True)):
         acc = {}
         for r in csv.DictReader(open(f)):
