@@ -210,6 +210,9 @@ def main():
     if not on_device:
         from mapper_amd import synth_device
         g = torch.from_numpy(np.concatenate(seqs)).cuda()
+        if not bool((g.cpu().numpy() == np.concatenate(seqs)).all()):
+            sys.stderr.write("bench.py: the copy of the sequences in HBM differs from the host's\n")
+            sys.exit(1)
         lens = np.array([len(x) for x in seqs], dtype=np.int64)
     d_offs = (torch.arange(w["reads"] + 1, dtype=torch.int64, device="cuda") * w["m"]).contiguous()
     d_chunks = []
@@ -273,6 +276,12 @@ def main():
     located_total = run_steps(args.steps, first=args.warmup)
     barrier()
     elapsed = time.perf_counter() - t0
+    # every read was drawn from the indexed sequences with at most tau substitutions, so every read is located at least
+    # once (at its origin): a run that located fewer mapped something else than it says, and must not print a line
+    if located_total < 0.9 * n_reads * args.steps:
+        sys.stderr.write("bench.py: %d located hits for %d reads drawn from the text: the reads and the index do not belong together\n"
+                         % (located_total, n_reads * args.steps))
+        sys.exit(1)
     if dist_on:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -400,7 +409,10 @@ def main():
                           "order": mean["order"], "chunk_on_device": mean["device_total"]},
             "hits_per_batch": {"list_entries": c["n_hits"], "list_length": c["list_length"], "located": c["n_locs"],
                                "verify_windows": W, "big_candidates": e["big_candidates"]},
+            # lane_fill counts the steps of the reference schedule only; a continuation (a node looked at again for its
+            # next sibling) occupies its lane for a pass as well: lane_busy counts both
             "occupancy": {"loop_passes": c["loop_passes"], "continuations": c["continuations"],
+                          "lane_busy": ((occ_steps + c["continuations"]) / (64.0 * c["loop_passes"])) if c["loop_passes"] else None,
                           "steps_from_jump_table": c["jumped_steps"], "steps_replayed_on_text": c["verify_steps"],
                           "steps_on_occ_table": occ_steps,
                           "lane_fill": (occ_steps / (64.0 * c["loop_passes"])) if c["loop_passes"] else None},

@@ -429,6 +429,8 @@ int gpumap_mapper_multi(const char *qfile, const gpumap_index *index, gpumap_ctx
 **   "sort_by_read"   1 = the sort of the located hits runs over the read's bits only and the hits of each read are put in
 **                    order where they lie; 0 = never; -1 = the default: where nearly every read has one hit (located hits
 **                    <= 1.25 x reads; with reads of hundreds of hits each the sort over the key is faster)
+**   "seed_candidates" 1 (default) = a seed whose entry of the jump table holds a single suffix leaves the search as a candidate
+**                    for the replay on the text at once; 0 = it takes a step on the Occ table first (same hits and step counts)
 **   "verify_tile"    entries of the search's output list a workgroup of k_verify takes (0 = the default, 512; at most 1024) */
 int gpumap_set_option(gpumap_ctx *ctx, const char *name, int64_t value);
 /* The names of the index's sequences (gpumap_index_view.seq_name; txt_pos_to_str prints them, src/index_txt.c:505), for

@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgpumap.so")
+LIB_PATH = os.environ.get("GPUMAP_LIB") or os.path.join(_HERE, "lib", "libgpumap.so")      # (GPUMAP_LIB: A/B runs of two builds)
 QUERY_PREFIX, QUERY_SUFFIX = 0, 1
 SRC_TEXT, SRC_DEVICE, PIPE_COMPACT = 1, 2, 4
 MAX_TAU = 7

@@ -444,6 +444,7 @@ extern "C" int gpumap_set_option(gpumap_ctx *ctx, const char *name, int64_t valu
    else if (!strcmp(name, "verify")) { GM_FAIL_IF(value != -1 && value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 16, "verify out of range (-1, 0, 1, 2, 4, 8, 16)."); ctx->verify = (int)value; }
    else if (!strcmp(name, "sort_all_bits")) ctx->sort_all_bits = value != 0;
    else if (!strcmp(name, "sort_by_read")) { GM_FAIL_IF(value < -1 || value > 1, "sort_by_read out of range (-1, 0, 1)."); ctx->sort_by_read = (int)value; }
+   else if (!strcmp(name, "seed_candidates")) { GM_FAIL_IF(value < 0 || value > 1, "seed_candidates out of range (0, 1)."); ctx->seed_candidates = (int)value; }
    else if (!strcmp(name, "verify_tile")) { GM_FAIL_IF(value < 0 || value > VERIFY_TILE_MAX, "verify_tile out of range (0 = default, at most 1024)."); ctx->verify_tile = (int)value; }
    else if (!strcmp(name, "trim")) { HIP_TRY(hipSetDevice(ctx->device)); ctx_free_spare_batches(ctx); }
    else if (!strcmp(name, "ann_trail_reuse")) ctx->ann_trail_reuse = value != 0;
@@ -1198,6 +1199,7 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
          A.jump2 = (const uint4 *)ctx->d_jump2; A.jump2_k = ctx->jump2_k;
          A.verify = use_verify;
          A.verify_stable = 1;
+         A.seed_cand = (use_verify >= 1 && ctx->seed_candidates) ? 1 : 0;
          A.read_row = sc ? b->read_row.as<const uint16_t>() : nullptr;
          A.sc_bound = sc ? b->sc_bound.as<const int64_t>() : nullptr;
          A.row_leaves = sc ? b->row_leaves.as<const uint8_t>() : nullptr;

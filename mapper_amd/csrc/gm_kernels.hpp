@@ -355,6 +355,7 @@ struct SearchArgs {
    int jump2_k;
    int verify;                  // nodes with sz <= verify (0, 1, 2 or 4) leave as candidates for k_verify
    int verify_stable;           // 1: those of more than two suffixes only when the last step left the interval as it was
+   int seed_cand;               // 1: a seed whose entry of the jump table holds one suffix leaves as a candidate at once
    uint32_t cursor_chunk;       // reads a wave reserves per atomic on the cursor (a multiple of its refill)
    // k_search<true> (blocksc_trail): per query its row of the phase tables (NO_ROW: not searched) and the bound of the
    // left block's hits (src/blocksearch.c:76), per row its number of leaf phases

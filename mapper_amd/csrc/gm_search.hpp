@@ -184,8 +184,8 @@ __global__ void __launch_bounds__(WG_THREADS) k_search(SearchArgs A)
    uint64_t mm = 0;
    uint32_t read = 0, meta = 0;
    int pos = 0;
-   uint32_t qword = 0;          // four query symbols around pos
-   int qword_at = -1;           // pos >> 2 of the cached word, -1 = none
+   uint4 qword = make_uint4(0, 0, 0, 0);   // sixteen query symbols around pos (one load per 16 letters of a walk: a load
+   int qword_at = -1;                      // per four letters was a fifth of the kernel's requests to the L2); pos >> 4 of them, -1 = none
    unsigned long long ext_count = 0;
    uint32_t jump_steps = 0;     // extension steps of this lane's seeds that the jump table stood in for
 #ifdef GM_STEP_HIST
@@ -226,7 +226,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_search(SearchArgs A)
                   const unsigned long long base = res_base;
                   res_base += (unsigned long long)got; res_left -= (uint32_t)got;
                   int r = lane / seeds_per, leaf = lane - r * seeds_per;
-                  bool mk = r < got;
+                  bool mk = r < got, seed_cand = false;
                   Node packed;
                   for (int k = 0; k < 8; k++) packed.w[k] = 0;
                   if (mk) {
@@ -272,12 +272,17 @@ __global__ void __launch_bounds__(WG_THREADS) k_search(SearchArgs A)
                               if (!SC || (uint32_t)leaf >= count_from) jump_steps += e.w >> 24;
                               sd.pos -= jk;
                               mk = sd.sz > 0;
+                              // one suffix left at the table's entry: a candidate for k_verify as it stands (the pass that took it
+                              // there one letter later cost a line of the Occ table per seed of a unique place)
+                              seed_cand = !SC && A.seed_cand && sd.sz == 1;
                            }
                         }
                         pack_node(sd, packed);
+                        if (seed_cand) packed.w[5] |= 1u << META_CAND;
                      }
                   }
-                  wave_push<QCAP, SPILL_CHUNK>(wq, mk, packed, lane);
+                  wave_push<QCAP, SPILL_CHUNK>(wq, mk && !seed_cand, packed, lane);
+                  if (!SC && A.seed_cand) hit_emit(A, hr, mk && seed_cand, packed, lane);
                }
             }
             wave_sync();
@@ -335,9 +340,9 @@ __global__ void __launch_bounds__(WG_THREADS) k_search(SearchArgs A)
          quad_fetch<0>(occ, b1 << 6, need1m, sub16, f10); quad_fetch<1>(occ, b1 << 6, need1m, sub16, f11);
          quad_fetch<2>(occ, b1 << 6, need1m, sub16, f12); quad_fetch<3>(occ, b1 << 6, need1m, sub16, f13);
       }
-      if (have && (pos >> 2) != qword_at) {
-         qword_at = pos >> 2;
-         qword = *reinterpret_cast<const uint32_t *>(A.reads + (size_t)read * A.stride + (pos & ~3));
+      if (have && (pos >> 4) != qword_at) {
+         qword_at = pos >> 4;
+         qword = *reinterpret_cast<const uint4 *>(A.reads + (size_t)read * A.stride + (pos & ~15));    // (rows are multiples of 128 bytes)
       }
 
       uint32_t rel0[SYMS], rel1[SYMS];
@@ -355,7 +360,8 @@ __global__ void __launch_bounds__(WG_THREADS) k_search(SearchArgs A)
       pin(g0); pin(g1); pin(g2); pin(g3);
       lane_rank(g0, g1, g2, g3, (int)(e1 & (BLOCK_POS - 1)), rel1);
       wave_sync();
-      const int qc = (int)((qword >> (8 * (pos & 3))) & 0xff);
+      const uint32_t qsel = (pos & 8) ? ((pos & 4) ? qword.w : qword.z) : ((pos & 4) ? qword.y : qword.x);
+      const int qc = (int)((qsel >> (8 * (pos & 3))) & 0xff);
 
       // ------------------------------------------------------------ bwt_query_all, src/index_bwt.c:262-273
       const int sb0 = (int)(e0 >> SUPER_LOG), sb1 = (int)(e1 >> SUPER_LOG);

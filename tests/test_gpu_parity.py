@@ -131,8 +131,10 @@ def test_verify_path_matches_reference_dump(workdir, name, tau):
     codes, offs = common.encode_reads(reads)
     ref = po.HitDump.load(os.path.join(common.GOLDEN, "%s.tau%d.bin" % (name, tau)))
     want_ext = orc.map_batch(codes, offs, tau, threads=2).n_ext
-    for verify in (16, 4, 2, 1, 0):                  # nodes of up to four / of one or two suffixes / of one suffix / none finished on the text
+    # (seed_candidates: a seed whose entry of the jump table holds one suffix goes to k_verify at once, or takes a step first)
+    for verify, seed in ((16, 1), (4, 1), (4, 0), (2, 1), (1, 1), (1, 0), (0, 1)):   # nodes of up to four / of one or two suffixes / of one suffix / none finished on the text
         ctx.set_option("verify", verify)
+        ctx.set_option("seed_candidates", seed)
         b = ctx.upload(codes, offs)
         c = b.run(tau)
         h = b.fetch()
@@ -174,8 +176,9 @@ def test_verify_at_the_ends_of_the_text_and_at_separators(workdir):
     offs = np.concatenate(([0], np.cumsum([len(r) for r in reads]))).astype(np.int64)
     for tau in (0, 1, 2, 3):
         d = orc.map_batch(codes, offs, tau, threads=2)
-        for verify in (16, 4, 2, 1, 0):
+        for verify, seed in ((16, 1), (4, 1), (4, 0), (2, 1), (1, 1), (1, 0), (0, 1)):
             ctx.set_option("verify", verify)
+            ctx.set_option("seed_candidates", seed)
             h = ctx.map_batch(codes, offs, tau)
             assert np.array_equal(h.status, d.status)
             assert np.array_equal(h.located(), d.located())
