@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--verify", type=int, default=-1, help="option 'verify' of the library (-1 = its default by text size)")
     ap.add_argument("--verify-tile", type=int, default=0, help="option 'verify_tile' of the library (0 = its default)")
     ap.add_argument("--jump-k", type=int, default=-2, help="option 'jump_k' of the library (-2 = leave its default)")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="gpumap_set_option on the context (A/B runs)")
     ap.add_argument("--device-build", action="store_true", help="generate and index in HBM also for the small workloads")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N > 1 "
                     "on a box with fewer GPUs than ranks: ranks then share devices)")
@@ -194,6 +195,8 @@ def main():
         ctx.set_option("verify_tile", args.verify_tile)
     if args.jump_k != -2:
         ctx.set_option("jump_k", args.jump_k)
+    for o in args.opt:
+        ctx.set_option(o.split("=")[0], int(o.split("=")[1]))
 
     # this rank's shard: its own reads (weak scaling).  n_chunks distinct chunks of reads_per_gpu reads each, their
     # LETTERS and offsets resident in HBM before the timed region starts (8 x 12.5 M = the 100 M reads of config 4

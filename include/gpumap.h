@@ -428,7 +428,9 @@ int gpumap_mapper_multi(const char *qfile, const gpumap_index *index, gpumap_ctx
 **                    score and up to three low bits of the position where that saves a pass; short runs are ordered after)
 **   "sort_by_read"   1 = the sort of the located hits runs over the read's bits only and the hits of each read are put in
 **                    order where they lie; 0 = never; -1 = the default: where nearly every read has one hit (located hits
-**                    <= 1.25 x reads; with reads of hundreds of hits each the sort over the key is faster)
+**                    <= 1.25 x reads; with reads of hundreds of hits each the sort over the key is faster);
+**                    2 = the sort runs over the key's top 16 bits (segments of consecutive reads) and a workgroup orders each
+**                    segment in LDS (faster for a chunk alone on the device, slower in the pipeline: not the default)
 **   "seed_candidates" 1 (default) = a seed whose entry of the jump table holds a single suffix leaves the search as a candidate
 **                    for the replay on the text at once; 0 = it takes a step on the Occ table first (same hits and step counts)
 **   "verify_tile"    entries of the search's output list a workgroup of k_verify takes (0 = the default, 512; at most 1024) */

@@ -60,6 +60,7 @@ struct gpumap_batch {
    int lines_per_rec = 0;
    int64_t first_line = 1, line_bytes = 0;
    bool have_lines = false;
+   DevBuf seg_first;                 // k_seg_first: where the segments of the sort by segments begin
    DevBuf big_start, big_cnt;        // k_order_first: the runs of keys it left to k_order_big
    DevBuf sc_flags, sc_alias;        // gpumap_ann_build with the reference's reuse of searches (sc_plan)
    struct AnnPlanHost *sc_plan = nullptr;     // not owned; set by gpumap_ann_build around its runs
@@ -443,7 +444,7 @@ extern "C" int gpumap_set_option(gpumap_ctx *ctx, const char *name, int64_t valu
    else if (!strcmp(name, "jump_bytes")) { GM_FAIL_IF(value < 0, "jump_bytes out of range."); ctx->jump_budget = value; HIP_TRY(hipSetDevice(ctx->device)); GM_FAIL_IF(gm_ctx_build_jump(ctx, -1) != 0, "cannot build the jump table."); }
    else if (!strcmp(name, "verify")) { GM_FAIL_IF(value != -1 && value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 16, "verify out of range (-1, 0, 1, 2, 4, 8, 16)."); ctx->verify = (int)value; }
    else if (!strcmp(name, "sort_all_bits")) ctx->sort_all_bits = value != 0;
-   else if (!strcmp(name, "sort_by_read")) { GM_FAIL_IF(value < -1 || value > 1, "sort_by_read out of range (-1, 0, 1)."); ctx->sort_by_read = (int)value; }
+   else if (!strcmp(name, "sort_by_read")) { GM_FAIL_IF(value < -1 || value > 2, "sort_by_read out of range (-1, 0, 1, 2)."); ctx->sort_by_read = (int)value; }
    else if (!strcmp(name, "seed_candidates")) { GM_FAIL_IF(value < 0 || value > 1, "seed_candidates out of range (0, 1)."); ctx->seed_candidates = (int)value; }
    else if (!strcmp(name, "verify_tile")) { GM_FAIL_IF(value < 0 || value > VERIFY_TILE_MAX, "verify_tile out of range (0 = default, at most 1024)."); ctx->verify_tile = (int)value; }
    else if (!strcmp(name, "trim")) { HIP_TRY(hipSetDevice(ctx->device)); ctx_free_spare_batches(ctx); }
@@ -1462,12 +1463,42 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
          int begin_bit = 0;
          const bool by_read = !ctx->sort_all_bits && end_bit < 64 && (ctx->sort_by_read == 1 || (ctx->sort_by_read < 0 && L <= R + R / 4));
          if (by_read) begin_bit = pos_bits + 4;
-         for (int drop = 0; drop <= 3 && begin_bit == 0; drop++)
-            if (cdiv(end_bit - (4 + drop), 8) < cdiv(end_bit, 8) && !ctx->sort_all_bits && end_bit < 64) begin_bit = 4 + drop;
-         HIP_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp, db, (int)L, begin_bit, end_bit, st));
-         HIP_TRY(b->cub_tmp.ensure(tmp));
-         HIP_TRY(hipcub::DeviceRadixSort::SortKeys(b->cub_tmp.p, tmp, db, (int)L, begin_bit, end_bit, st));
-         b->sorted_keys = db.Current();
+         // Second form of round 3 (sort_by_read = 2, not the default): two passes over the key's top 16 bits bring the hits of
+         // a segment of reads together (256 reads where a chunk has 2^24), and k_order_segments orders every segment in LDS
+         // by the rest of the key: the keys cross the memory 3 times instead of 7.  Measured at GRCh38 size: order 1.97 ->
+         // 1.66 ms for a chunk alone on the device, but 803-808 -> 787-793 M reads/s in the pipeline, where the ordering of
+         // a chunk runs beside the next chunk's search: the radix passes stream, the segments' kernel competes with the
+         // search for LDS and vector issue.  chr21 size (3 000 keys per segment, some beyond 8 192): 4.67 -> 5.17 ms.
+         const int seg_bits = std::min(read_bits, 16), seg_shift = end_bit - seg_bits;
+         const int64_t n_seg = ((std::max<int64_t>(R, 1) - 1) >> (read_bits - seg_bits)) + 1;
+         const bool by_seg = !by_read && !ctx->sort_all_bits && end_bit < 64 &&
+                             ctx->sort_by_read == 2;
+         if (by_seg) {
+            int lo = 4;
+            for (int drop = 1; drop <= 3 && lo == 4; drop++)
+               if (cdiv(seg_shift - (4 + drop), 8) < cdiv(seg_shift - 4, 8)) lo = 4 + drop;
+            HIP_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp, db, (int)L, seg_shift, end_bit, st));
+            HIP_TRY(b->cub_tmp.ensure(tmp));
+            HIP_TRY(hipcub::DeviceRadixSort::SortKeys(b->cub_tmp.p, tmp, db, (int)L, seg_shift, end_bit, st));
+            HIP_TRY(b->seg_first.ensure(4 * (size_t)(n_seg + 1)));
+            hipLaunchKernelGGL(k_seg_first, dim3((unsigned)cdiv(L, 256)), dim3(256), 0, st, (const unsigned long long *)db.Current(), L, seg_shift, n_seg,
+                               b->seg_first.as<uint32_t>());
+            hipLaunchKernelGGL(k_order_segments<4>, dim3((unsigned)n_seg), dim3(256), 0, st, db.Current(), db.Alternate(), b->seg_first.as<const uint32_t>(),
+                               lo, seg_shift, 0, false);
+            hipLaunchKernelGGL(k_order_segments<16>, dim3((unsigned)n_seg), dim3(256), 0, st, db.Current(), db.Alternate(), b->seg_first.as<const uint32_t>(),
+                               lo, seg_shift, 1024, false);
+            hipLaunchKernelGGL(k_order_segments<32>, dim3((unsigned)n_seg), dim3(256), 0, st, db.Current(), db.Alternate(), b->seg_first.as<const uint32_t>(),
+                               lo, seg_shift, 4096, true);
+            b->sorted_keys = db.Current();
+            begin_bit = lo;                                  // (the keys that agree from `lo` up are put in order by k_read_first / k_order_runs)
+         } else {
+            for (int drop = 0; drop <= 3 && begin_bit == 0; drop++)
+               if (cdiv(end_bit - (4 + drop), 8) < cdiv(end_bit, 8) && !ctx->sort_all_bits && end_bit < 64) begin_bit = 4 + drop;
+            HIP_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp, db, (int)L, begin_bit, end_bit, st));
+            HIP_TRY(b->cub_tmp.ensure(tmp));
+            HIP_TRY(hipcub::DeviceRadixSort::SortKeys(b->cub_tmp.p, tmp, db, (int)L, begin_bit, end_bit, st));
+            b->sorted_keys = db.Current();
+         }
          if (by_read) {
             const int64_t ob = cdiv(L, 256);
             HIP_TRY(b->big_start.ensure(4 * (size_t)ORDER_SLOT * (size_t)ob));

@@ -1428,6 +1428,115 @@ __global__ void __launch_bounds__(256) k_order_big(unsigned long long *keys, uns
    }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Round 3, second form: two radix passes over the top 16 bits of the key bring the hits of a SEGMENT of reads
+// together (256 consecutive reads where a chunk has 2^24 of them); a workgroup then orders each segment in LDS by
+// the rest of the key.  The traffic of the ordering stage goes from 7 passes over the keys to 2 + 1; what a
+// segment costs depends on its number of keys only, not on how they spread over its reads.
+//   k_seg_first      where each segment begins (a thread per key, as k_read_first)
+//   k_order_segments<E>  a workgroup per segment of up to 256 * E keys (launched for E = 4, 16, 32, each taking the segments
+//                    the one before left); longer segments by radix passes through the sort's other buffer
+// ------------------------------------------------------------------------------------------------
+__global__ void k_seg_first(const unsigned long long *keys, int64_t n, int shift, int64_t n_seg, uint32_t *seg_first)
+{
+   const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+   if (t >= n) return;
+   const int64_t s = (int64_t)(keys[t] >> shift);
+   const int64_t before = t == 0 ? -1 : (int64_t)(keys[t - 1] >> shift);
+   for (int64_t x = before + 1; x <= s && x <= n_seg; x++) seg_first[x] = (uint32_t)t;
+   if (t == n - 1)
+      for (int64_t x = s + 1; x <= n_seg; x++) seg_first[x] = (uint32_t)n;
+}
+
+// E keys per thread in registers (a segment of up to 256 * E keys), LSD passes of 8 bits over [lo_bit, shift): a wavefront
+// owns a quarter of the segment in order; a key's rank among the wavefront's keys of its digit comes from ballots
+// (which lanes hold the same digit) and a running count per wavefront and digit in LDS, the digit's base from a scan
+// over the 256 digits and the four wavefronts; the keys change places through one LDS array.  Stable, so the passes
+// add up to the order by all the bits.  (A bitonic network in LDS was the first form: 110 LDS accesses per key at
+// 1024 keys against 15 here; it ran at the speed of the LDS pipe, 1.0 ms for the segments of a GRCh38-size chunk.)
+template <int E>
+__global__ void __launch_bounds__(256) k_order_segments(unsigned long long *keys, unsigned long long *alt, const uint32_t *seg_first, int lo_bit, int shift,
+                                                        int len_above, bool longer_too)
+{
+   constexpr int CAP = 256 * E;
+   __shared__ unsigned long long s_keys[CAP];
+   __shared__ uint32_t s_wcnt[4][256];
+   __shared__ uint32_t s_hist[256];
+   __shared__ uint32_t s_part[4];
+   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+   const int64_t b = seg_first[blockIdx.x], e = seg_first[blockIdx.x + 1];
+   const int len = (int)min(e - b, (int64_t)CAP + 1);
+   if (len < 2 || len <= len_above) return;
+   if (e - b > CAP) {
+      if (longer_too) block_radix_run(keys, alt, b, e, lo_bit, shift, s_hist, s_wcnt, s_part);
+      return;
+   }
+   const int rounds = (len + 255) >> 8;                      // per wavefront; its keys are [wid * rounds * 64, (wid + 1) * rounds * 64) of the segment
+   const int first = wid * rounds * 64 + lane;
+   const unsigned long long lt = (1ull << lane) - 1ull;
+   unsigned long long k[E];
+   uint32_t rank[E];
+#pragma unroll
+   for (int r = 0; r < E; r++) {
+      const int i = first + r * 64;
+      k[r] = (r < rounds && i < len) ? keys[b + i] : 0ull;
+   }
+   for (int bit = lo_bit; bit < shift; bit += 8) {
+      const int nb = min(8, shift - bit);
+      const uint32_t mask = (1u << nb) - 1u;
+      for (int d = lane; d < 256; d += 64) s_wcnt[wid][d] = 0;
+      wave_sync();
+#pragma unroll
+      for (int r = 0; r < E; r++) {
+         if (r < rounds) {
+            const bool valid = first + r * 64 < len;
+            const uint32_t d = (uint32_t)(k[r] >> bit) & mask;
+            unsigned long long same = __ballot(valid);
+            for (int q = 0; q < nb; q++) {
+               const unsigned long long bb = __ballot((d >> q) & 1u);
+               same &= ((d >> q) & 1u) ? bb : ~bb;
+            }
+            const uint32_t below = (uint32_t)__popcll(same & lt);
+            uint32_t pre = 0;
+            if (valid) pre = s_wcnt[wid][d];
+            rank[r] = pre + below;
+            wave_sync();
+            if (valid && below == 0) s_wcnt[wid][d] = pre + (uint32_t)__popcll(same);
+            wave_sync();
+         }
+      }
+      __syncthreads();
+      {  // digit tid: its keys in the four wavefronts -> where each wavefront's keys of the digit begin
+         const uint32_t c0 = s_wcnt[0][tid], c1 = s_wcnt[1][tid], c2 = s_wcnt[2][tid], c3 = s_wcnt[3][tid];
+         const uint32_t v = c0 + c1 + c2 + c3;
+         uint32_t incl = v;
+         for (int o = 1; o < 64; o <<= 1) { const uint32_t x = (uint32_t)__shfl_up((int)incl, o); if (lane >= o) incl += x; }
+         if (lane == 63) s_part[wid] = incl;
+         __syncthreads();
+         uint32_t before = 0;
+         for (int w = 0; w < wid; w++) before += s_part[w];
+         const uint32_t ex = before + incl - v;
+         s_wcnt[0][tid] = ex; s_wcnt[1][tid] = ex + c0; s_wcnt[2][tid] = ex + c0 + c1; s_wcnt[3][tid] = ex + c0 + c1 + c2;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < E; r++)
+         if (r < rounds && first + r * 64 < len) {
+            const uint32_t d = (uint32_t)(k[r] >> bit) & mask;
+            s_keys[s_wcnt[wid][d] + rank[r]] = k[r];
+         }
+      __syncthreads();
+      if (bit + 8 < shift) {
+#pragma unroll
+         for (int r = 0; r < E; r++) {
+            const int i = first + r * 64;
+            if (r < rounds && i < len) k[r] = s_keys[i];
+         }
+      }
+   }
+   for (int i = tid; i < len; i += 256) keys[b + i] = s_keys[i];
+}
+
 // Compact results: the sorted keys are the output; only the CSR offsets of the reads are derived from them
 // (as k_unpack_locs does: the thread of the first key of a read writes that read's offset and those of the
 // reads without hits before it).

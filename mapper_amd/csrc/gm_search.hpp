@@ -133,6 +133,9 @@ __device__ __forceinline__ void lane_rank(const uint4 &s0, const uint4 &s1, cons
 // Keeps the compiler from carrying values derived from a block across the point where some lanes
 // replace the block (it would merge the two versions with a register move per derived value).
 __device__ __forceinline__ void pin(uint4 &v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+// Registers that the lanes which load nothing never look at: "defined" for the compiler without an instruction (48 moves
+// of zero per pass were 8 % of the kernel's vector instructions; plainly uninitialised they cost 90 registers).
+__device__ __forceinline__ void any_value(uint4 &v) { asm volatile("" : "=v"(v.x), "=v"(v.y), "=v"(v.z), "=v"(v.w)); }
 
 constexpr int PH_LDS_ROWS = 8;       // phase-record rows (read lengths) kept in LDS; others are read from global memory
 
@@ -333,7 +336,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_search(SearchArgs A)
       const uint32_t b0 = (uint32_t)(e0 >> BLOCK_POS_LOG), b1 = (uint32_t)(e1 >> BLOCK_POS_LOG);
       const unsigned long long need1m = __ballot(have && b1 != b0);
       uint4 f00, f01, f02, f03, f10, f11, f12, f13;
-      f00 = f01 = f02 = f03 = f10 = f11 = f12 = f13 = make_uint4(0, 0, 0, 0);   // (leaving these undefined costs 90 registers)
+      any_value(f00); any_value(f01); any_value(f02); any_value(f03); any_value(f10); any_value(f11); any_value(f12); any_value(f13);
       quad_fetch<0>(occ, b0 << 6, havem, sub16, f00); quad_fetch<1>(occ, b0 << 6, havem, sub16, f01);
       quad_fetch<2>(occ, b0 << 6, havem, sub16, f02); quad_fetch<3>(occ, b0 << 6, havem, sub16, f03);
       if (need1m) {
@@ -346,7 +349,8 @@ __global__ void __launch_bounds__(WG_THREADS) k_search(SearchArgs A)
       }
 
       uint32_t rel0[SYMS], rel1[SYMS];
-      uint4 g0 = make_uint4(0, 0, 0, 0), g1 = g0, g2 = g0, g3 = g0;
+      uint4 g0, g1, g2, g3;
+      any_value(g0); any_value(g1); any_value(g2); any_value(g3);
       quad_stage<0>(stage_w, havem, f00); quad_stage<1>(stage_w, havem, f01);
       quad_stage<2>(stage_w, havem, f02); quad_stage<3>(stage_w, havem, f03);
       wave_sync();

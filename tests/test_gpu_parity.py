@@ -468,7 +468,7 @@ def test_sort_that_skips_low_bits_gives_the_same_order(workdir, n_reads):
     codes = np.concatenate(reads)
     offs = np.arange(0, 40 * (n_reads + 1), 40, dtype=np.int64)
     d = orc.map_batch(codes, offs, 2, threads=8)
-    for all_bits, by_read in ((1, 0), (0, 0), (0, 1)):
+    for all_bits, by_read in ((1, 0), (0, 0), (0, 1), (0, 2)):
         ctx.set_option("sort_all_bits", all_bits)
         ctx.set_option("sort_by_read", by_read)
         for compact in (0, 1):                       # (compact results: the runs are ordered inside k_read_first)
@@ -511,7 +511,7 @@ def test_reads_with_thousands_of_hits_come_in_order(workdir):
     d = orc.map_batch(codes, offs, 2, threads=8)
     per_read = np.bincount(d.located()[:, 0], minlength=len(reads))
     assert per_read.max() > 8000 and (per_read > 4096).sum() >= 10
-    for all_bits, by_read in ((0, 1), (0, 0), (1, 0)):
+    for all_bits, by_read in ((0, 1), (0, 2), (0, 0), (1, 0)):
         ctx.set_option("sort_all_bits", all_bits)
         ctx.set_option("sort_by_read", by_read)
         for compact in (0, 1):
