@@ -495,13 +495,13 @@ extern "C" gpumap_ctx *gpumap_build_device(const uint8_t *codes, int codes_on_de
       int64_t *d_seq_beg = nullptr;
       if (!codes_on_device) {
          HIP_TRY(A.get(&own_codes, (size_t)total_codes));
-         HIP_TRY(hipMemcpy(own_codes, codes, (size_t)total_codes, hipMemcpyHostToDevice));
+         HIP_TRY(hipMemcpyAsync(own_codes, codes, (size_t)total_codes, hipMemcpyHostToDevice, st));      // (on the kernels' stream: see gm_ctx_common_init)
          d_codes = own_codes;
       }
       HIP_TRY(A.get(&d_seq_beg, (size_t)seq_cnt));
-      HIP_TRY(hipMemcpy(d_seq_beg, seq_beg.data(), 8 * (size_t)seq_cnt, hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpyAsync(d_seq_beg, seq_beg.data(), 8 * (size_t)seq_cnt, hipMemcpyHostToDevice, st));
       HIP_TRY(hipMalloc((void **)&text, (size_t)n + 16));                    // k_verify reads whole words
-      HIP_TRY(hipMemset(text + n, SYMS, 16));
+      HIP_TRY(hipMemsetAsync(text + n, SYMS, 16, st));
       ctx->d_text = text;                                   // released by gpumap_destroy (or below)
       hipLaunchKernelGGL(k_build_text, dim3(grid_for(n, 256)), dim3(256), 0, st, d_codes, (const int64_t *)d_seq_beg, seq_cnt, tlen0, text);
       HIP_TRY(hipGetLastError());
@@ -545,7 +545,7 @@ extern "C" gpumap_ctx *gpumap_build_device(const uint8_t *codes, int codes_on_de
          ctx->c_host[0] = (u64)ctx->wil_cnt;                               // src/index_bwt.c:575-582
          for (int j = 1; j <= SYMS; j++) ctx->c_host[j] = ctx->c_host[j - 1] + tot[j - 1];
          GM_FAIL_IF((int64_t)ctx->c_host[SYMS] != n, "internal error: symbol counts do not add up to the text length.");
-         HIP_TRY(hipMemcpy(d_c, ctx->c_host, 8 * (SYMS + 1), hipMemcpyHostToDevice));
+         HIP_TRY(hipMemcpyAsync(d_c, ctx->c_host, 8 * (SYMS + 1), hipMemcpyHostToDevice, st));
       }
       // ---- packed suffix array (with the stale word the in-place packer leaves behind, see gm_index.cpp)
       {
@@ -596,14 +596,15 @@ extern "C" int gpumap_reference_fetch(gpumap_ctx *ctx, uint64_t *occ, uint64_t c
    HIP_TRY(hipSetDevice(ctx->device));
    if (occ) {
       GM_FAIL_IF(ctx->d_ref_occ == nullptr, "the context does not keep the reference Occ array.");
-      HIP_TRY(hipMemcpy(occ, ctx->d_ref_occ, 8 * (size_t)ctx->ref_occ_words, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpyAsync(occ, ctx->d_ref_occ, 8 * (size_t)ctx->ref_occ_words, hipMemcpyDeviceToHost, ctx->stream));
    }
    if (c) memcpy(c, ctx->c_host, 8 * (SYMS + 1));
-   if (sa) HIP_TRY(hipMemcpy(sa, ctx->d_sa, 8 * (size_t)ctx->sar_len, hipMemcpyDeviceToHost));
+   if (sa) HIP_TRY(hipMemcpyAsync(sa, ctx->d_sa, 8 * (size_t)ctx->sar_len, hipMemcpyDeviceToHost, ctx->stream));
    if (text) {
       GM_FAIL_IF(ctx->d_text == nullptr, "the context does not keep the text.");
-      HIP_TRY(hipMemcpy(text, ctx->d_text, (size_t)ctx->ix.n, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpyAsync(text, ctx->d_text, (size_t)ctx->ix.n, hipMemcpyDeviceToHost, ctx->stream));
    }
+   HIP_TRY(hipStreamSynchronize(ctx->stream));
    return 0;
 failure_return:
    return -1;

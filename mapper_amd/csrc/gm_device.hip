@@ -164,7 +164,13 @@ int gm_ctx_common_init(gpumap_ctx *ctx, int device)
    ctx->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
    HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
    HIP_TRY(hipMalloc((void **)&ctx->d_sym_table, 256));
-   HIP_TRY(hipMemcpy(ctx->d_sym_table, ctx->sym_table, 256, hipMemcpyHostToDevice));
+   // (Every upload and fill of the set-up goes on the stream of the kernels that use it, and the host waits for that stream.
+   // The runtime's synchronous calls work on the null stream, which a non-blocking stream is not ordered with: a fill
+   // that returns before it is done (hipMemset does) then lands on top of what a kernel on the context's stream has
+   // written since.  Seen under rocprofv3's counter collection, where every operation takes its time: the second
+   // context of a process searched with a zeroed superblock table.)
+   HIP_TRY(hipMemcpyAsync(ctx->d_sym_table, ctx->sym_table, 256, hipMemcpyHostToDevice, ctx->stream));
+   HIP_TRY(hipStreamSynchronize(ctx->stream));
    return 0;
 failure_return:
    return -1;
@@ -272,7 +278,7 @@ int gm_ctx_repack(gpumap_ctx *ctx, const uint64_t *d_ref_occ, const uint64_t *d_
    ctx->tables_bytes = ctx->tables_words * 8;
    HIP_TRY(hipMalloc(&ctx->d_occ, (size_t)ctx->occ_bytes));
    HIP_TRY(hipMalloc(&ctx->d_tables, (size_t)ctx->tables_bytes));
-   HIP_TRY(hipMemset(ctx->d_tables, 0, (size_t)ctx->tables_bytes));
+   HIP_TRY(hipMemsetAsync(ctx->d_tables, 0, (size_t)ctx->tables_bytes, ctx->stream));
    {
       int64_t n_ref_words = cdiv(ix.n, mark_intv * 64) * mark_intv;
       int64_t g1 = cdiv(std::max<int64_t>(ix.n_super, SYMS), 64);
@@ -332,18 +338,19 @@ extern "C" gpumap_ctx *gpumap_create(const gpumap_index_view *v, int device)
       ctx->sar_len = v->sar_len;
       ctx->sa_bytes = (v->sar_len + 1) * 8;           // one spare word: an entry read may touch word+1
       HIP_TRY(hipMalloc(&ctx->d_sa, (size_t)ctx->sa_bytes));
-      HIP_TRY(hipMemset(ctx->d_sa, 0, (size_t)ctx->sa_bytes));
-      HIP_TRY(hipMemcpy(ctx->d_sa, v->sa, (size_t)v->sar_len * 8, hipMemcpyHostToDevice));
+      HIP_TRY(hipMemsetAsync(ctx->d_sa, 0, (size_t)ctx->sa_bytes, ctx->stream));
+      HIP_TRY(hipMemcpyAsync(ctx->d_sa, v->sa, (size_t)v->sar_len * 8, hipMemcpyHostToDevice, ctx->stream));
       if (v->text) {        // the text lets k_verify finish unique nodes; without it the search runs on the Occ table alone
          HIP_TRY(hipMalloc(&ctx->d_text, (size_t)v->txt_len + 16));          // k_verify reads whole words
-         HIP_TRY(hipMemset((char *)ctx->d_text + v->txt_len, SYMS, 16));
-         HIP_TRY(hipMemcpy(ctx->d_text, v->text, (size_t)v->txt_len, hipMemcpyHostToDevice));
+         HIP_TRY(hipMemsetAsync((char *)ctx->d_text + v->txt_len, SYMS, 16, ctx->stream));
+         HIP_TRY(hipMemcpyAsync(ctx->d_text, v->text, (size_t)v->txt_len, hipMemcpyHostToDevice, ctx->stream));
       }
       // K0: upload the reference layout verbatim, repack on the device, drop the copy
       HIP_TRY(hipMalloc(&d_ref, (size_t)v->occ_length * 8));
-      HIP_TRY(hipMemcpy(d_ref, v->occ, (size_t)v->occ_length * 8, hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpyAsync(d_ref, v->occ, (size_t)v->occ_length * 8, hipMemcpyHostToDevice, ctx->stream));
       HIP_TRY(hipMalloc(&d_c, 8 * (SYMS + 1)));
-      HIP_TRY(hipMemcpy(d_c, v->c, 8 * (SYMS + 1), hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpyAsync(d_c, v->c, 8 * (SYMS + 1), hipMemcpyHostToDevice, ctx->stream));
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
       GM_FAIL_IF(gm_ctx_repack(ctx, (const uint64_t *)d_ref, (const uint64_t *)d_c, v->occ_mark_intv, v->seq_beg, v->seq_cnt) != 0,
                  "cannot repack the Occ table.");
       HIP_TRY(hipFree(d_ref)); d_ref = nullptr;
@@ -426,7 +433,8 @@ extern "C" gpumap_ctx *gpumap_create_from_device(const gpumap_devindex *dev, con
    ctx->ix.sa = (const uint64_t *)ctx->d_sa;
    ctx->ix.seq_beg = (const int64_t *)((const uint64_t *)ctx->d_tables + TAB_SBASE + SYMS * h.n_super);
    ctx->seq_beg_host.resize((size_t)h.seq_cnt);
-   HIP_TRY(hipMemcpy(ctx->seq_beg_host.data(), ctx->ix.seq_beg, 8 * (size_t)h.seq_cnt, hipMemcpyDeviceToHost));
+   HIP_TRY(hipMemcpyAsync(ctx->seq_beg_host.data(), ctx->ix.seq_beg, 8 * (size_t)h.seq_cnt, hipMemcpyDeviceToHost, ctx->stream));
+   HIP_TRY(hipStreamSynchronize(ctx->stream));
    GM_FAIL_IF(gm_ctx_build_jump(ctx, getenv("GPUMAP_JUMP_K") ? atoi(getenv("GPUMAP_JUMP_K")) : -1) != 0, "cannot build the jump table.");
    return ctx;
 failure_return:
@@ -614,8 +622,9 @@ extern "C" int gpumap_set_seq_names(gpumap_ctx *ctx, const char *const *names, i
       HIP_TRY(hipSetDevice(ctx->device));
       HIP_TRY(ctx->d_names.ensure(blob.size() + 16));
       HIP_TRY(ctx->d_name_off.ensure(4 * off.size()));
-      HIP_TRY(hipMemcpy(ctx->d_names.p, blob.data(), blob.size(), hipMemcpyHostToDevice));
-      HIP_TRY(hipMemcpy(ctx->d_name_off.p, off.data(), 4 * off.size(), hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpyAsync(ctx->d_names.p, blob.data(), blob.size(), hipMemcpyHostToDevice, ctx->stream));
+      HIP_TRY(hipMemcpyAsync(ctx->d_name_off.p, off.data(), 4 * off.size(), hipMemcpyHostToDevice, ctx->stream));
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
    }
    return 0;
 failure_return:
@@ -1964,7 +1973,8 @@ extern "C" int gpumap_ann_build(gpumap_ctx *ctx, int kmer, int tau, uint8_t *tab
          AnnCarry fresh;
          for (int c = 0; c < 2; c++) { fresh.prev[c] = fresh.ol[c] = fresh.oll[c] = -1; fresh.ol_bound[c] = 0; fresh.ol_tl[c] = 0; }
          HIP_TRY(plan.carry.ensure(sizeof fresh));
-         HIP_TRY(hipMemcpy(plan.carry.p, &fresh, sizeof fresh, hipMemcpyHostToDevice));
+         HIP_TRY(hipMemcpyAsync(plan.carry.p, &fresh, sizeof fresh, hipMemcpyHostToDevice, st));
+         HIP_TRY(hipStreamSynchronize(st));
          plan.q_sa = q_sa.as<const int64_t>(); plan.kmer = kmer; plan.depth = depth;
          b->sc_plan = &plan; b->extra_factor = 2;
       }
