@@ -773,7 +773,12 @@ void gm_batch_set_streams(gpumap_batch *b, void *run, void *copy, void *up, void
 void gm_batch_set_hook(gpumap_batch *b, std::function<void()> on_searched) { b->on_searched = std::move(on_searched); }
 
 // Waits until everything this thread has put on `st` so far is done (not for what other batches add meanwhile).
-#define GM_SYNC(b, st) do { HIP_TRY(hipEventRecord((b)->ev_sync, (st))); HIP_TRY(hipEventSynchronize((b)->ev_sync)); } while (0)
+static const bool gm_sync_debug = getenv("GPUMAP_SYNC_DEBUG") != nullptr;      // (debug aid: which wait a thread sits in)
+#define GM_SYNC(b, st) do { \
+      if (gm_sync_debug) fprintf(stderr, "[sync] batch %p line %d stream %p: wait\n", (void *)(b), __LINE__, (void *)(st)); \
+      HIP_TRY(hipEventRecord((b)->ev_sync, (st))); HIP_TRY(hipEventSynchronize((b)->ev_sync)); \
+      if (gm_sync_debug) fprintf(stderr, "[sync] batch %p line %d: over\n", (void *)(b), __LINE__); \
+   } while (0)
 
 // Encoding of a filled batch: the lengths seen (k_read_lengths, read back by gm_batch_fill) size the read
 // matrix; letters (or codes) -> codes in fixed-stride rows (k_encode) and the rows as bit planes (k_pack_planes).

@@ -5,6 +5,9 @@
 # Each pass is its own process with its own time limit; the script stops at the first failure.
 # pass 0 runs twice: as the product runs (chunks overlap on the pipeline's streams) and with GPUMAP_PIPE_OVERLAP=0
 # (every launch alone on the device: the duration bench.py's HIP events measure).
+# The counter passes run without stream priorities: counter collection serialises the kernels of all queues, which makes the
+# high-priority queues of the pipeline wait for the others, and a high-priority queue that waits for a lower one can stall
+# this platform for good (seen: tests/test_gpu_mapper.py under --pmc, 3 runs of 4; none without priorities).
 # PMC_ONLY="7 8" runs only the named counter passes (and no stats pass).  COMMIT=<id> is recorded in the summary.
 # Raw rocprofv3 output stays in /tmp (gpurun_out/ is limited to 64 MiB); summaries go to OUTDIR.
 out=$1; shift; wl=$1; shift
@@ -27,7 +30,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum
            "TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_TCP_LATENCY_sum TCP_TOTAL_ACCESSES_sum TA_TA_BUSY_sum TA_DATA_STALLED_BY_TC_CYCLES_sum GRBM_GUI_ACTIVE"; do
   i=$((i+1))
   if [ -n "$PMC_ONLY" ] && ! echo " $PMC_ONLY " | grep -q " $i "; then continue; fi
-  timeout -s KILL 300 rocprofv3 --pmc $grp --output-format csv -d $raw/pmc$i -- $B > $raw/pmc$i.json 2> $raw/pmc$i.err || { echo "pmc pass $i ($grp) failed"; tail -5 $raw/pmc$i.err; exit 1; }
+  GPUMAP_PIPE_PRIO=0 GPUMAP_PIPE_POST_PRIO=0 timeout -s KILL 300 rocprofv3 --pmc $grp --output-format csv -d $raw/pmc$i -- $B > $raw/pmc$i.json 2> $raw/pmc$i.err || { echo "pmc pass $i ($grp) failed"; tail -5 $raw/pmc$i.err; exit 1; }
 done
 python3 $R/tools/profile_summary.py $raw > $final/summary.json || exit 1
 [ -z "$PMC_ONLY" ] && cp "$(ls -S $(find $raw/stats -name "*kernel_stats.csv") | head -1)" $final/kernel_stats.csv   # (the largest: the bench, not the gather microbenchmark it starts)
