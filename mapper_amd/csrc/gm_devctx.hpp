@@ -75,7 +75,7 @@ struct gpumap_ctx {
    // nodes whose interval holds one suffix are finished against the text (k_verify) when the text is in
    // HBM (d_text) and the caller wants located hits only
    bool sort_all_bits = false;    // option "sort_all_bits": 1 = the radix sort of the located hits runs over every bit of the keys (no k_order_runs)
-   int sort_by_read = -1;         // option "sort_by_read": 1 = the sort runs over the read's bits and the hits of a read are ordered in place, 0 = never, -1 = where nearly every read has one hit, 2 = by segments of reads (k_order_segments)
+   int sort_by_read = -1;         // option "sort_by_read": 1 = the sort runs over the read's bits and the hits of a read are ordered in place, 0 = never either, 1 = by read, 2 = by segments of reads (k_order_segments), -1 = by read where nearly every read has one hit, by segments where they are small
    int seed_candidates = 1;       // option "seed_candidates": a seed whose entry of the jump table holds one suffix goes to k_verify at once
    int verify_tile = 0;           // option "verify_tile": entries of the hit list a block of k_verify takes (0: 512)
    int verify = -1;               // option "verify": 0 off, 1 nodes of one suffix, 2 also of two, -1 by the size of the text

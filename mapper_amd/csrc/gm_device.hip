@@ -35,6 +35,11 @@ struct gpumap_batch {
    // beside the next chunk's encoding and search, which wait for memory requests most of the time.
    hipStream_t st_post = nullptr;
    std::function<void()> on_searched;
+   // ... and the pipeline holds the NEXT run's k_search back until this run's sort has been enqueued (before_search of the
+   // next batch waits for on_ordering of this one): k_search is persistent and takes every CU's LDS; a sort that arrives after
+   // it has started finds no room until it ends, and the chunks' results then come back in bursts (17.3 instead of 14.8 ms
+   // per chunk; which of the two a run got was a matter of a host round trip taking 0.2 or 1 ms)
+   std::function<void()> before_search, on_ordering;
    hipEvent_t ev_sync = nullptr, ev_up = nullptr;
    int64_t n_reads = 0;
    int stride = 0, maxlen = 1;
@@ -771,6 +776,10 @@ void gm_batch_set_streams(gpumap_batch *b, void *run, void *copy, void *up, void
 }
 
 void gm_batch_set_hook(gpumap_batch *b, std::function<void()> on_searched) { b->on_searched = std::move(on_searched); }
+void gm_batch_set_gate(gpumap_batch *b, std::function<void()> before_search, std::function<void()> on_ordering)
+{
+   b->before_search = std::move(before_search); b->on_ordering = std::move(on_ordering);
+}
 
 // Waits until everything this thread has put on `st` so far is done (not for what other batches add meanwhile).
 static const bool gm_sync_debug = getenv("GPUMAP_SYNC_DEBUG") != nullptr;      // (debug aid: which wait a thread sits in)
@@ -1224,6 +1233,7 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
             int64_t k = R / std::max<int64_t>(1, n_waves * 8 * rpr);           // at least 8 reservations per wave: balance at the end
             A.cursor_chunk = (uint32_t)(rpr * std::min<int64_t>(16, std::max<int64_t>(1, k)));
          }
+         if (b->before_search) { b->before_search(); b->before_search = nullptr; }
          if (R > 0) {
             if (sc) hipLaunchKernelGGL(k_search<true>, dim3((unsigned)n_wg), dim3(WG_THREADS), search_lds, st, A);
             else hipLaunchKernelGGL(k_search<false>, dim3((unsigned)n_wg), dim3(WG_THREADS), search_lds, st, A);
@@ -1477,16 +1487,18 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
          int begin_bit = 0;
          const bool by_read = !ctx->sort_all_bits && end_bit < 64 && (ctx->sort_by_read == 1 || (ctx->sort_by_read < 0 && L <= R + R / 4));
          if (by_read) begin_bit = pos_bits + 4;
-         // Second form of round 3 (sort_by_read = 2, not the default): two passes over the key's top 16 bits bring the hits of
-         // a segment of reads together (256 reads where a chunk has 2^24), and k_order_segments orders every segment in LDS
-         // by the rest of the key: the keys cross the memory 3 times instead of 7.  Measured at GRCh38 size: order 1.97 ->
-         // 1.66 ms for a chunk alone on the device, but 803-808 -> 787-793 M reads/s in the pipeline, where the ordering of
-         // a chunk runs beside the next chunk's search: the radix passes stream, the segments' kernel competes with the
-         // search for LDS and vector issue.  chr21 size (3 000 keys per segment, some beyond 8 192): 4.67 -> 5.17 ms.
+         // Second form of round 3 (sort_by_read = 2; the default where a segment holds 512 .. 2 048 keys on average): two
+         // passes over the key's top 16 bits bring the hits of a segment of reads together (256 reads where a chunk has
+         // 2^24), and k_order_segments orders every segment in LDS by the rest of the key: the keys cross the memory 3 times
+         // instead of 7.  Measured at GRCh38 size (850 keys per segment): order 1.97 -> 1.66 ms, 774-782 -> 798-801 M reads/s
+         // in the pipeline.  (A first comparison in the pipeline said the opposite; it was made before the pipeline held the
+         // next k_search back until the sort is enqueued, when a run got one of two regimes by chance.)
+         // chr21 size (3 000 keys per segment, some beyond the 8 192 a workgroup takes): 4.67 -> 5.17 ms: not there.  4 M reads
+         // of 150 nt (200 keys per segment): 0.64 -> 0.68 ms: not there either.
          const int seg_bits = std::min(read_bits, 16), seg_shift = end_bit - seg_bits;
          const int64_t n_seg = ((std::max<int64_t>(R, 1) - 1) >> (read_bits - seg_bits)) + 1;
          const bool by_seg = !by_read && !ctx->sort_all_bits && end_bit < 64 &&
-                             ctx->sort_by_read == 2;
+                             (ctx->sort_by_read == 2 || (ctx->sort_by_read < 0 && n_seg >= 4096 && L / n_seg >= 512 && L / n_seg <= 2048));
          if (by_seg) {
             int lo = 4;
             for (int drop = 1; drop <= 3 && lo == 4; drop++)
@@ -1513,6 +1525,7 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
             HIP_TRY(hipcub::DeviceRadixSort::SortKeys(b->cub_tmp.p, tmp, db, (int)L, begin_bit, end_bit, st));
             b->sorted_keys = db.Current();
          }
+         if (b->on_ordering) { b->on_ordering(); b->on_ordering = nullptr; }
          if (by_read) {
             const int64_t ob = cdiv(L, 256);
             HIP_TRY(b->big_start.ensure(4 * (size_t)ORDER_SLOT * (size_t)ob));

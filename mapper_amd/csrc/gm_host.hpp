@@ -112,3 +112,4 @@ void gm_batch_set_streams(gpumap_batch *b, void *run, void *copy, void *up, void
 int  gm_ctx_pipe_streams(gpumap_ctx *ctx, void **run, void **copy, void **up, void **post);
 // Called by gm_batch_run when the search of the run is over and only locate / order / formatting remain (on the post stream).
 void gm_batch_set_hook(gpumap_batch *b, std::function<void()> on_searched);
+void gm_batch_set_gate(gpumap_batch *b, std::function<void()> before_search, std::function<void()> on_ordering);

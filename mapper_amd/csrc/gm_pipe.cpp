@@ -44,7 +44,8 @@ struct gpumap_pipe {
    // context's kernel stream: every chunk then takes as long as all of them together, in lock-step (results came back in
    // bursts of `depth`, the first after 58 ms instead of 18).  Uploads and result copies still overlap the runs.
    std::vector<uint64_t> ctx_submitted, ctx_turn;
-   bool ordered = true, overlap = true;
+   std::vector<uint64_t> ctx_ordering;      // runs of the context whose sort has been enqueued (or that ended without one)
+   bool ordered = true, overlap = true, gate = true;
    // the last thread that took or released a result (gpumap_pipe_submit: can anyone but the submitting thread free a slot?)
    bool consumer_seen = false;
    std::thread::id consumer_tid;
@@ -81,9 +82,21 @@ static void pipe_worker(gpumap_pipe *p, Slot *s)
          { std::lock_guard<std::mutex> l(p->m); p->ctx_turn[(size_t)s->ctx_index]++; }
          p->cv.notify_all();
       };
+      // The k_search of this run is not launched before the sorts of the runs before it have been enqueued (see gm_batch_set_gate).
+      auto ordering_enqueued = [&] {
+         { std::lock_guard<std::mutex> l(p->m); uint64_t &k = p->ctx_ordering[(size_t)s->ctx_index]; k = std::max(k, s->run_seq + 1); }
+         p->cv.notify_all();
+      };
+      auto wait_for_ordering = [&] {
+         std::unique_lock<std::mutex> l(p->m);
+         p->cv.wait(l, [&] { return p->ctx_ordering[(size_t)s->ctx_index] >= s->run_seq || p->stop; });
+      };
       if (p->overlap) gm_batch_set_hook(s->batch, pass_turn);
+      if (p->overlap && p->ordered && p->gate) gm_batch_set_gate(s->batch, wait_for_ordering, ordering_enqueued);
       if (rc == 0) rc = gm_batch_run(s->ctx, s->batch, p->tau, 0, p->result_flags);
       gm_batch_set_hook(s->batch, nullptr);
+      gm_batch_set_gate(s->batch, nullptr, nullptr);
+      ordering_enqueued();
       pass_turn();
       if (dbg) fprintf(stderr, "[pipe %.2f] slot %d: fetch (rc %d)\n", now_ms(), id, rc);
       if (rc == 0) rc = gm_batch_fetch(s->ctx, s->batch, &s->hits, p->result_flags);
@@ -133,6 +146,8 @@ extern "C" gpumap_pipe *gpumap_pipe_create(gpumap_ctx *const *ctxs, int n_ctx, i
    p->slots = std::vector<Slot>((size_t)depth * (size_t)n_ctx);
    p->ctx_submitted.assign((size_t)n_ctx, 0);
    p->ctx_turn.assign((size_t)n_ctx, 0);
+   p->ctx_ordering.assign((size_t)n_ctx, 0);
+   p->gate = !getenv("GPUMAP_PIPE_GATE") || atoi(getenv("GPUMAP_PIPE_GATE")) != 0;      // (0: tuning aid)
    if (getenv("GPUMAP_PIPE_GRACE_MS")) p->grace_ms = std::max(0, atoi(getenv("GPUMAP_PIPE_GRACE_MS")));
    p->overlap = !getenv("GPUMAP_PIPE_OVERLAP") || atoi(getenv("GPUMAP_PIPE_OVERLAP")) != 0;
    p->ordered = !getenv("GPUMAP_PIPE_ORDERED") || atoi(getenv("GPUMAP_PIPE_ORDERED")) != 0;      // (0: tuning aid, the runs interleave)
