@@ -1509,14 +1509,17 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
             HIP_TRY(b->seg_first.ensure(4 * (size_t)(n_seg + 1)));
             hipLaunchKernelGGL(k_seg_first, dim3((unsigned)cdiv(L, 256)), dim3(256), 0, st, (const unsigned long long *)db.Current(), L, seg_shift, n_seg,
                                b->seg_first.as<uint32_t>());
+            // (the workgroup of a segment also orders the keys that agree from `lo` up and writes the CSR offsets of its reads)
+            SegOut so;
+            so.read_first = b->read_first.as<int64_t>(); so.n_reads = R; so.n_keys = L; so.read_shift = pos_bits + 4; so.seg_reads_log = read_bits - seg_bits;
             hipLaunchKernelGGL(k_order_segments<4>, dim3((unsigned)n_seg), dim3(256), 0, st, db.Current(), db.Alternate(), b->seg_first.as<const uint32_t>(),
-                               lo, seg_shift, 0, false);
+                               lo, seg_shift, -1, false, so);
             hipLaunchKernelGGL(k_order_segments<16>, dim3((unsigned)n_seg), dim3(256), 0, st, db.Current(), db.Alternate(), b->seg_first.as<const uint32_t>(),
-                               lo, seg_shift, 1024, false);
+                               lo, seg_shift, 1024, false, so);
             hipLaunchKernelGGL(k_order_segments<32>, dim3((unsigned)n_seg), dim3(256), 0, st, db.Current(), db.Alternate(), b->seg_first.as<const uint32_t>(),
-                               lo, seg_shift, 4096, true);
+                               lo, seg_shift, 4096, true, so);
             b->sorted_keys = db.Current();
-            begin_bit = lo;                                  // (the keys that agree from `lo` up are put in order by k_read_first / k_order_runs)
+            begin_bit = 0;
          } else {
             for (int drop = 0; drop <= 3 && begin_bit == 0; drop++)
                if (cdiv(end_bit - (4 + drop), 8) < cdiv(end_bit, 8) && !ctx->sort_all_bits && end_bit < 64) begin_bit = 4 + drop;
@@ -1565,8 +1568,9 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
             hipLaunchKernelGGL(k_format_write, dim3((unsigned)cdiv(L, 256)), dim3(256), 0, st, F);
             b->have_lines = true;
          } else if (compact) {
-            hipLaunchKernelGGL(k_read_first, dim3((unsigned)cdiv(L, 256)), dim3(256), 0, st, sk, L, pos_bits, R,
-                               b->read_first.as<int64_t>(), begin_bit);
+            if (!by_seg)
+               hipLaunchKernelGGL(k_read_first, dim3((unsigned)cdiv(L, 256)), dim3(256), 0, st, sk, L, pos_bits, R,
+                                  b->read_first.as<int64_t>(), begin_bit);
          } else {
             if (begin_bit > 0) hipLaunchKernelGGL(k_order_runs, dim3((unsigned)cdiv(L, 256)), dim3(256), 0, st, sk, L, begin_bit);
             for (DevBuf *x : {&b->loc_read, &b->loc_pos, &b->loc_fwd, &b->loc_seq, &b->loc_seqpos}) HIP_TRY(x->ensure(8 * (size_t)L));

@@ -1454,9 +1454,60 @@ __global__ void k_seg_first(const unsigned long long *keys, int64_t n, int shift
 // over the 256 digits and the four wavefronts; the keys change places through one LDS array.  Stable, so the passes
 // add up to the order by all the bits.  (A bitonic network in LDS was the first form: 110 LDS accesses per key at
 // 1024 keys against 15 here; it ran at the speed of the LDS pipe, 1.0 ms for the segments of a GRCh38-size chunk.)
+// What follows the sort of a segment, by the workgroup that holds it: the keys that agree from `lo_bit` up (bits the
+// passes left out) are put in order, and the CSR offsets of the segment's reads are written (what k_read_first does
+// for the whole array: the thread of the first key of a read writes that read's offset and those of the reads
+// without hits before it; the reads behind the segment's last key get its end).
+struct SegOut {
+   int64_t *read_first;       // nullptr: the caller derives the offsets itself
+   int64_t n_reads, n_keys;
+   int read_shift;            // the read's bits begin here
+   int seg_reads_log;         // a segment holds 2^this reads
+};
+
+__device__ __forceinline__ void segment_finish(unsigned long long *k /* LDS or global */, int len, int64_t first_key, int64_t seg, int lo_bit,
+                                               const SegOut &o, int tid)
+{
+   if (lo_bit > 4) {
+      for (int i = tid; i < len; i += 256) {
+         const unsigned long long g = k[i] >> lo_bit;
+         if (i > 0 && (k[i - 1] >> lo_bit) == g) continue;
+         int e = i + 1;
+         while (e < len && (k[e] >> lo_bit) == g) e++;
+         for (int x = i + 1; x < e; x++) {
+            const unsigned long long v = k[x];
+            int j = x;
+            while (j > i && k[j - 1] > v) { k[j] = k[j - 1]; j--; }
+            if (j != x) k[j] = v;
+         }
+      }
+      __syncthreads();
+   }
+   if (o.read_first == nullptr) return;
+   const int64_t r_lo = seg << o.seg_reads_log, r_hi = min(o.n_reads, (seg + 1) << o.seg_reads_log);
+   for (int i = tid; i < len; i += 256) {
+      const int64_t r = (int64_t)(k[i] >> o.read_shift);
+      const int64_t before = i == 0 ? r_lo - 1 : (int64_t)(k[i - 1] >> o.read_shift);
+      for (int64_t x = before + 1; x <= r; x++) o.read_first[x] = first_key + i;
+   }
+   if (tid == 0) {
+      const int64_t last = len == 0 ? r_lo - 1 : (int64_t)(k[len - 1] >> o.read_shift);
+      for (int64_t x = last + 1; x < r_hi; x++) o.read_first[x] = first_key + len;
+      if (r_hi == o.n_reads) o.read_first[o.n_reads] = o.n_keys;
+   }
+}
+
+// E keys per thread in registers (a segment of up to 256 * E keys), LSD passes of 8 bits over [lo_bit, shift): a wavefront
+// owns a quarter of the segment in order; a key's rank among the wavefront's keys of its digit comes from ballots
+// (which lanes hold the same digit) and a running count per wavefront and digit in LDS, the digit's base from a scan
+// over the 256 digits and the four wavefronts; the keys change places through one LDS array.  Stable, so the passes
+// add up to the order by all the bits.  (A bitonic network in LDS was the first form: 110 LDS accesses per key at
+// 1024 keys against 15 here; it ran at the speed of the LDS pipe, 1.0 ms for the segments of a GRCh38-size chunk.)
+// A launch takes the segments of more than len_above and at most 256 * E keys (-1: from empty ones on), the launch with
+// longer_too also the longer ones (radix passes through the sort's other buffer).
 template <int E>
 __global__ void __launch_bounds__(256) k_order_segments(unsigned long long *keys, unsigned long long *alt, const uint32_t *seg_first, int lo_bit, int shift,
-                                                        int len_above, bool longer_too)
+                                                        int len_above, bool longer_too, SegOut out)
 {
    constexpr int CAP = 256 * E;
    __shared__ unsigned long long s_keys[CAP];
@@ -1466,9 +1517,20 @@ __global__ void __launch_bounds__(256) k_order_segments(unsigned long long *keys
    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
    const int64_t b = seg_first[blockIdx.x], e = seg_first[blockIdx.x + 1];
    const int len = (int)min(e - b, (int64_t)CAP + 1);
-   if (len < 2 || len <= len_above) return;
+   if (len <= len_above) return;
    if (e - b > CAP) {
-      if (longer_too) block_radix_run(keys, alt, b, e, lo_bit, shift, s_hist, s_wcnt, s_part);
+      if (longer_too) {
+         block_radix_run(keys, alt, b, e, lo_bit, shift, s_hist, s_wcnt, s_part);
+         __threadfence_block();
+         __syncthreads();
+         segment_finish(keys + b, (int)(e - b), b, (int64_t)blockIdx.x, lo_bit, out, tid);
+      }
+      return;
+   }
+   if (len < 2) {
+      if (tid == 0 && len == 1) s_keys[0] = keys[b];
+      __syncthreads();
+      segment_finish(s_keys, len, b, (int64_t)blockIdx.x, 4, out, tid);
       return;
    }
    const int rounds = (len + 255) >> 8;                      // per wavefront; its keys are [wid * rounds * 64, (wid + 1) * rounds * 64) of the segment
@@ -1534,6 +1596,8 @@ __global__ void __launch_bounds__(256) k_order_segments(unsigned long long *keys
          }
       }
    }
+   segment_finish(s_keys, len, b, (int64_t)blockIdx.x, lo_bit, out, tid);
+   __syncthreads();
    for (int i = tid; i < len; i += 256) keys[b + i] = s_keys[i];
 }
 
