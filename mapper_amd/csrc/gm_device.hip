@@ -1514,8 +1514,10 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
             so.read_first = b->read_first.as<int64_t>(); so.n_reads = R; so.n_keys = L; so.read_shift = pos_bits + 4; so.seg_reads_log = read_bits - seg_bits;
             hipLaunchKernelGGL(k_order_segments<4>, dim3((unsigned)n_seg), dim3(256), 0, st, db.Current(), db.Alternate(), b->seg_first.as<const uint32_t>(),
                                lo, seg_shift, -1, false, so);
-            hipLaunchKernelGGL(k_order_segments<16>, dim3((unsigned)n_seg), dim3(256), 0, st, db.Current(), db.Alternate(), b->seg_first.as<const uint32_t>(),
+            hipLaunchKernelGGL(k_order_segments<8>, dim3((unsigned)n_seg), dim3(256), 0, st, db.Current(), db.Alternate(), b->seg_first.as<const uint32_t>(),
                                lo, seg_shift, 1024, false, so);
+            hipLaunchKernelGGL(k_order_segments<16>, dim3((unsigned)n_seg), dim3(256), 0, st, db.Current(), db.Alternate(), b->seg_first.as<const uint32_t>(),
+                               lo, seg_shift, 2048, false, so);
             hipLaunchKernelGGL(k_order_segments<32>, dim3((unsigned)n_seg), dim3(256), 0, st, db.Current(), db.Alternate(), b->seg_first.as<const uint32_t>(),
                                lo, seg_shift, 4096, true, so);
             b->sorted_keys = db.Current();
