@@ -430,8 +430,8 @@ int gpumap_mapper_multi(const char *qfile, const gpumap_index *index, gpumap_ctx
 **                    order where they lie; 0 = never; -1 = the default: where nearly every read has one hit (located hits
 **                    <= 1.25 x reads; with reads of hundreds of hits each the sort over the key is faster);
 **                    2 = the sort runs over the key's top 16 bits (segments of consecutive reads) and a workgroup orders each
-**                    segment in LDS (also part of the default: where a segment holds 512 .. 2 048 keys on average and
-**                    there are 4 096 segments or more: GRCh38 size with 12.5 M reads, not chr21 size)
+**                    segment in LDS (also part of the default: where reads have up to six hits on average and there are
+**                    4 096 segments or more: GRCh38 size with 12.5 M reads, not chr21 size)
 **   "seed_candidates" 1 (default) = a seed whose entry of the jump table holds a single suffix leaves the search as a candidate
 **                    for the replay on the text at once; 0 = it takes a step on the Occ table first (same hits and step counts)
 **   "verify_tile"    entries of the search's output list a workgroup of k_verify takes (0 = the default, 512; at most 1024) */

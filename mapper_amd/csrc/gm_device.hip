@@ -1487,18 +1487,24 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
          int begin_bit = 0;
          const bool by_read = !ctx->sort_all_bits && end_bit < 64 && (ctx->sort_by_read == 1 || (ctx->sort_by_read < 0 && L <= R + R / 4));
          if (by_read) begin_bit = pos_bits + 4;
-         // Second form of round 3 (sort_by_read = 2; the default where a segment holds 512 .. 2 048 keys on average): two
+         // Second form of round 3 (sort_by_read = 2; the default where reads have up to six hits on average): two
          // passes over the key's top 16 bits bring the hits of a segment of reads together (256 reads where a chunk has
          // 2^24), and k_order_segments orders every segment in LDS by the rest of the key: the keys cross the memory 3 times
          // instead of 7.  Measured at GRCh38 size (850 keys per segment): order 1.97 -> 1.66 ms, 774-782 -> 798-801 M reads/s
          // in the pipeline.  (A first comparison in the pipeline said the opposite; it was made before the pipeline held the
          // next k_search back until the sort is enqueued, when a run got one of two regimes by chance.)
-         // chr21 size (3 000 keys per segment, some beyond the 8 192 a workgroup takes): 4.67 -> 5.17 ms: not there.  4 M reads
-         // of 150 nt (200 keys per segment): 0.64 -> 0.68 ms: not there either.
-         const int seg_bits = std::min(read_bits, 16), seg_shift = end_bit - seg_bits;
+         // chr21 size (12 hits per read on average, thousands for some: the hits of one read cannot be split, and segments beyond
+         // the 8 192 keys a workgroup takes go through the other buffer): 4.67 -> 5.2 .. 6.9 ms with 16 .. 20 bits: not there.
+         // 4 M reads of 150 nt with 14 bits: 0.65 -> 0.60 ms.
+         // (as many of the key's top bits as make segments of about 768 keys: 16 at GRCh38 size, 18 at chr21 size, where a read
+         // has 12 hits on average)
+         int seg_bits = std::min(read_bits, 8);
+         while (seg_bits < read_bits && (L >> seg_bits) > 768) seg_bits++;
+         if (getenv("GPUMAP_SEG_BITS")) seg_bits = std::max(1, std::min(read_bits, atoi(getenv("GPUMAP_SEG_BITS"))));      // (tuning aid)
+         const int seg_shift = end_bit - seg_bits;
          const int64_t n_seg = ((std::max<int64_t>(R, 1) - 1) >> (read_bits - seg_bits)) + 1;
          const bool by_seg = !by_read && !ctx->sort_all_bits && end_bit < 64 &&
-                             (ctx->sort_by_read == 2 || (ctx->sort_by_read < 0 && n_seg >= 4096 && L / n_seg >= 512 && L / n_seg <= 2048));
+                             (ctx->sort_by_read == 2 || (ctx->sort_by_read < 0 && n_seg >= 4096 && L <= 6 * R));
          if (by_seg) {
             int lo = 4;
             for (int drop = 1; drop <= 3 && lo == 4; drop++)
