@@ -747,21 +747,23 @@ int gm_ctx_pipe_streams(gpumap_ctx *ctx, void **run, void **copy, void **up, voi
       if (ctx->pipe_run == nullptr) {
          int least = 0, greatest = 0;
          HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));      // numerically: greatest <= 0 <= least
-         // (a LOW-priority upload stream deadlocked: the run stream's wait for the upload's event kept the
-         // low-priority queue from being scheduled once several contexts shared the device.  Nothing waits on the
-         // device for a stream of lower priority now.)
-         // Measured at GRCh38 size, 12.5 M reads per chunk, chunks resident in HBM: copy stream high, upload stream
-         // normal 20.6 ms per chunk (19.5 without any copy); both high 22.0; from page-locked host memory 46 / 51 ms.
-         const int mode = getenv("GPUMAP_PIPE_PRIO") ? atoi(getenv("GPUMAP_PIPE_PRIO")) : 1;      // tuning aid: 0 = no priorities, 2 = upload high too
+         // No stream priorities (round 3).  What they did depended on things outside the library: in a process of its own,
+         // with the copy and post streams of high priority, a chunk's ordering ran beside the next chunk's search (steps of
+         // 14.4 ms at GRCh38 size) and the result copies got what was left (20 ms each); with all streams of normal priority
+         // the copies ran at the link's speed and the kernels one after the other (15.3 ms).  In a process that holds an RCCL
+         // communicator (bench.py --gpus N) it was the other way round, and mixed settings (copy high, post normal) there gave
+         // copies that only ran while no kernel did: 24.5 ms per step (tools/debug/prio_ab4.sh, profiles/r3_stream_priorities.txt).
+         // Priorities also were what stalled the first form of the pipeline (a low-priority upload stream that the run stream
+         // waited for) and what stalls it under rocprofv3 --pmc.  GPUMAP_PIPE_PRIO=1 / GPUMAP_PIPE_POST_PRIO=1 bring them back.
+         // The order in which the streams are made matters as well (it decides which hardware queues they share): run, post,
+         // copy, upload.
+         const int mode = getenv("GPUMAP_PIPE_PRIO") ? atoi(getenv("GPUMAP_PIPE_PRIO")) : 0;      // tuning aid: 1 = result copies high, 2 = uploads high too
+         const int post_mode = getenv("GPUMAP_PIPE_POST_PRIO") ? atoi(getenv("GPUMAP_PIPE_POST_PRIO")) : 0;      // tuning aid: 1 = high priority
          (void)least;
          HIP_TRY(hipStreamCreateWithFlags(&ctx->pipe_run, hipStreamNonBlocking));
+         HIP_TRY(hipStreamCreateWithPriority(&ctx->pipe_post, hipStreamNonBlocking, post_mode >= 1 ? greatest : 0));
          HIP_TRY(hipStreamCreateWithPriority(&ctx->pipe_copy, hipStreamNonBlocking, mode >= 1 ? greatest : 0));
          HIP_TRY(hipStreamCreateWithPriority(&ctx->pipe_up, hipStreamNonBlocking, mode >= 2 ? greatest : 0));
-         // (measured at GRCh38 size, 12.5 M reads per chunk: no overlap 758 M reads/s; post stream of normal priority 793 M,
-         // of high priority 803 .. 808 M.  With k_verify moved over as well, beside the next chunk's k_search: 710 M: both
-         // wait for the same queue of memory requests.)
-         const int post_mode = getenv("GPUMAP_PIPE_POST_PRIO") ? atoi(getenv("GPUMAP_PIPE_POST_PRIO")) : 1;      // tuning aid: 0 = normal priority
-         HIP_TRY(hipStreamCreateWithPriority(&ctx->pipe_post, hipStreamNonBlocking, post_mode >= 1 ? greatest : 0));
       }
    }
    *run = ctx->pipe_run; *copy = ctx->pipe_copy; *up = ctx->pipe_up; *post = ctx->pipe_post;
