@@ -749,21 +749,64 @@ int gm_ctx_pipe_streams(gpumap_ctx *ctx, void **run, void **copy, void **up, voi
          HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));      // numerically: greatest <= 0 <= least
          // No stream priorities (round 3).  What they did depended on things outside the library: in a process of its own,
          // with the copy and post streams of high priority, a chunk's ordering ran beside the next chunk's search (steps of
-         // 14.4 ms at GRCh38 size) and the result copies got what was left (20 ms each); with all streams of normal priority
-         // the copies ran at the link's speed and the kernels one after the other (15.3 ms).  In a process that holds an RCCL
-         // communicator (bench.py --gpus N) it was the other way round, and mixed settings (copy high, post normal) there gave
-         // copies that only ran while no kernel did: 24.5 ms per step (tools/debug/prio_ab4.sh, profiles/r3_stream_priorities.txt).
-         // Priorities also were what stalled the first form of the pipeline (a low-priority upload stream that the run stream
-         // waited for) and what stalls it under rocprofv3 --pmc.  GPUMAP_PIPE_PRIO=1 / GPUMAP_PIPE_POST_PRIO=1 bring them back.
-         // The order in which the streams are made matters as well (it decides which hardware queues they share): run, post,
-         // copy, upload.
+         // 14.4 ms at GRCh38 size); with all streams of normal priority the kernels ran one after the other (15.3 ms).  In a
+         // process that holds an RCCL communicator (bench.py --gpus N) it was the other way round, and mixed settings (copy
+         // high, post normal) there gave copies that only ran while no kernel did: 24.5 ms per step (tools/debug/prio_ab4.sh,
+         // profiles/r3_stream_priorities.txt).  What the priorities really changed was which streams shared a hardware
+         // queue; that is now looked at directly (below).  Priorities also were what stalled the first form of the pipeline
+         // (a low-priority upload stream that the run stream waited for) and what stalls it under rocprofv3 --pmc.
+         // GPUMAP_PIPE_PRIO=1 / GPUMAP_PIPE_POST_PRIO=1 bring them back.
          const int mode = getenv("GPUMAP_PIPE_PRIO") ? atoi(getenv("GPUMAP_PIPE_PRIO")) : 0;      // tuning aid: 1 = result copies high, 2 = uploads high too
          const int post_mode = getenv("GPUMAP_PIPE_POST_PRIO") ? atoi(getenv("GPUMAP_PIPE_POST_PRIO")) : 0;      // tuning aid: 1 = high priority
          (void)least;
          HIP_TRY(hipStreamCreateWithFlags(&ctx->pipe_run, hipStreamNonBlocking));
-         HIP_TRY(hipStreamCreateWithPriority(&ctx->pipe_post, hipStreamNonBlocking, post_mode >= 1 ? greatest : 0));
-         HIP_TRY(hipStreamCreateWithPriority(&ctx->pipe_copy, hipStreamNonBlocking, mode >= 1 ? greatest : 0));
-         HIP_TRY(hipStreamCreateWithPriority(&ctx->pipe_up, hipStreamNonBlocking, mode >= 2 ? greatest : 0));
+         // Streams share hardware queues (GPU_MAX_HW_QUEUES, 4 by default), work on one queue is serial, and which queue a
+         // stream gets depends on every stream the process has made before.  The post, copy and upload streams are
+         // therefore CHOSEN: of a few candidates the first that is seen to run beside the streams made so far (kernels
+         // that spin for a millisecond on those, an empty kernel on the candidate: does it end before they do?).
+         static const bool probe = !(getenv("GPUMAP_PIPE_PROBE") && atoi(getenv("GPUMAP_PIPE_PROBE")) == 0);
+         static const bool probe_dbg = getenv("GPUMAP_PIPE_DEBUG") != nullptr;
+         hipEvent_t ea[3] = {nullptr, nullptr, nullptr}, eb = nullptr;
+         for (auto &e : ea) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+         HIP_TRY(hipEventCreateWithFlags(&eb, hipEventDisableTiming));
+         auto side_by_side = [&](const std::vector<hipStream_t> &beside, hipStream_t st) -> int {      // 1 yes, 0 no, -1 error
+            for (int rep = 0; rep < 2; rep++) {                           // (both tries must say no for a 0)
+               int n = 0;
+               for (hipStream_t o : beside) {
+                  hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, o, (long long)2000000);
+                  if (hipEventRecord(ea[n++], o) != hipSuccess) return -1;
+               }
+               hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, st, (long long)0);
+               if (hipEventRecord(eb, st) != hipSuccess) return -1;
+               if (hipEventSynchronize(eb) != hipSuccess) return -1;
+               bool overtook = true;
+               for (int k = 0; k < n; k++) if (hipEventQuery(ea[k]) != hipErrorNotReady) overtook = false;
+               for (int k = 0; k < n; k++) if (hipEventSynchronize(ea[k]) != hipSuccess) return -1;
+               if (overtook) return 1;
+            }
+            return 0;
+         };
+         auto choose = [&](hipStream_t *out, int priority, const std::vector<hipStream_t> &beside, const char *what) -> hipError_t {
+            std::vector<hipStream_t> cand;
+            int pick = -1;
+            for (int k = 0; k < (probe ? 8 : 1) && pick < 0; k++) {
+               hipStream_t st = nullptr;
+               hipError_t e = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, priority);
+               if (e != hipSuccess) return e;
+               cand.push_back(st);
+               if (!probe || side_by_side(beside, st) == 1) pick = k;
+            }
+            if (probe_dbg) fprintf(stderr, "[pipe] %s stream: candidate %d of %zu%s\n", what, pick < 0 ? 0 : pick, cand.size(), pick < 0 ? " (none ran beside the others)" : "");
+            if (pick < 0) pick = 0;
+            *out = cand[(size_t)pick];
+            for (size_t k = 0; k < cand.size(); k++) if ((int)k != pick) (void)hipStreamDestroy(cand[k]);
+            return hipSuccess;
+         };
+         HIP_TRY(choose(&ctx->pipe_post, post_mode >= 1 ? greatest : 0, {ctx->pipe_run}, "post"));
+         HIP_TRY(choose(&ctx->pipe_copy, mode >= 1 ? greatest : 0, {ctx->pipe_run, ctx->pipe_post}, "copy"));
+         HIP_TRY(choose(&ctx->pipe_up, mode >= 2 ? greatest : 0, {ctx->pipe_run, ctx->pipe_post, ctx->pipe_copy}, "upload"));
+         for (auto &e : ea) (void)hipEventDestroy(e);
+         (void)hipEventDestroy(eb);
       }
    }
    *run = ctx->pipe_run; *copy = ctx->pipe_copy; *up = ctx->pipe_up; *post = ctx->pipe_post;

@@ -1601,6 +1601,13 @@ __global__ void __launch_bounds__(256) k_order_segments(unsigned long long *keys
    for (int i = tid; i < len; i += 256) keys[b + i] = s_keys[i];
 }
 
+// Keeps one wavefront busy for `cycles` of the shader clock (gm_ctx_pipe_streams: do two streams run side by side?).
+__global__ void k_spin(long long cycles)
+{
+   const long long t0 = clock64();
+   while (clock64() - t0 < cycles) __builtin_amdgcn_s_sleep(8);
+}
+
 // Compact results: the sorted keys are the output; only the CSR offsets of the reads are derived from them
 // (as k_unpack_locs does: the thread of the first key of a read writes that read's offset and those of the
 // reads without hits before it).
