@@ -87,6 +87,11 @@ def main():
                     help="run the N > 1 code path with any N, also 1: process group (RCCL), broadcast of the index arrays, a replica "
                          "created from the broadcast buffers (gpumap_create_from_device) that serves the timed region, replica check")
     args = ap.parse_args()
+    # stdout carries the one JSON line and nothing else: libraries that write there (RCCL prints its version banner to
+    # stdout when a communicator is made) go to stderr for the length of the run
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -428,7 +433,10 @@ def main():
             out["pcie_inclusive"] = pcie_inclusive(ma, ctx, codes, offs, w, args.depth)
         if want_cpu:
             out["cpu_baseline"] = cpu_baseline(root_ctx if on_device else None, base, codes, offs, w, args.cpu_seconds, gpu_ctx=ctx)
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     batch.close()
     pipe.close()
     if dist_on:

@@ -104,7 +104,9 @@ def test_bench_runs_its_distributed_path_on_one_gpu():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "ecoli", "--reads", "20000", "--steps", "3", "--warmup", "1",
                         "--force-dist", "--no-pcie", "--cpu-seconds", "1"], capture_output=True, text=True, timeout=280, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
-    line = json.loads(r.stdout.strip().splitlines()[-1])
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 1, lines[:5]                       # one JSON line and nothing else (RCCL's banner goes to stderr)
+    line = json.loads(lines[0])
     assert line["n_gpus"] == 1 and line["value"] > 0
     assert line["replica_check"]["identical_across_ranks"] and line["replica_check"]["identical_to_oracle"]
     assert line["setup_s"]["rccl_broadcast"] > 0 and line["setup_s"]["replica_from_device"] > 0
