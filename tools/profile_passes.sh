@@ -5,9 +5,10 @@
 # Each pass is its own process with its own time limit; the script stops at the first failure.
 # pass 0 runs twice: as the product runs (chunks overlap on the pipeline's streams) and with GPUMAP_PIPE_OVERLAP=0
 # (every launch alone on the device: the duration bench.py's HIP events measure).
-# The counter passes run without stream priorities: counter collection serialises the kernels of all queues, which makes the
-# high-priority queues of the pipeline wait for the others, and a high-priority queue that waits for a lower one can stall
-# this platform for good (seen: tests/test_gpu_mapper.py under --pmc, 3 runs of 4; none without priorities).
+# The counter passes run without stream priorities (the library's default since; set here in case the environment says
+# otherwise): counter collection serialises the kernels of all queues, which makes a high-priority queue wait for the others,
+# and a high-priority queue that waits for a lower one can stall this platform for good (seen: tests/test_gpu_mapper.py under
+# --pmc with the priorities of before, 3 runs of 4; none without).
 # PMC_ONLY="7 8" runs only the named counter passes (and no stats pass).  COMMIT=<id> is recorded in the summary.
 # Raw rocprofv3 output stays in /tmp (gpurun_out/ is limited to 64 MiB); summaries go to OUTDIR.
 out=$1; shift; wl=$1; shift
