@@ -12,8 +12,9 @@ batch is fixed, value = reads of all ranks / max-over-ranks time).
 
 A "step" is one pass of the hot path over one chunk of reads whose letters are resident in HBM when the
 timed region starts: encode (k_encode, k_pack_planes) + search (k_search, k_verify) +
-suffix-array locate + ordering + the copy of the hits to page-locked host memory (compact results: sorted
-8-byte keys + CSR offsets).  Steps cycle over 8 distinct chunks and go through the library's pipeline
+suffix-array locate + ordering + the copy of the hits to page-locked host memory (packed results: per hit, in
+read order and by ascending position, 5 bytes = text position and score; per read a 4-byte offset and a status
+byte; --results compact: 8-byte keys, 8-byte offsets and status).  Steps cycle over 8 distinct chunks and go through the library's pipeline
 (gpumap_pipe), so that the copy of one chunk's hits overlaps the next chunk's kernels.
 Default workload: the GRCh38-size index of config 4 (synthetic, generated and indexed in HBM).
 
@@ -79,6 +80,8 @@ def main():
     ap.add_argument("--verify", type=int, default=-1, help="option 'verify' of the library (-1 = its default by text size)")
     ap.add_argument("--verify-tile", type=int, default=0, help="option 'verify_tile' of the library (0 = its default)")
     ap.add_argument("--jump-k", type=int, default=-2, help="option 'jump_k' of the library (-2 = leave its default)")
+    ap.add_argument("--results", default="packed", choices=["packed", "compact"],
+                    help="form of the results that cross the link in the timed region (GPUMAP_PIPE_PACKED / GPUMAP_PIPE_COMPACT)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="gpumap_set_option on the context (A/B runs)")
     ap.add_argument("--device-build", action="store_true", help="generate and index in HBM also for the small workloads")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N > 1 "
@@ -249,10 +252,11 @@ def main():
 
     # ---- the timed region: encode + search + locate + order + D2H of the hits, chunk after chunk through
     # the library's pipeline (gpumap_pipe: `depth` batch objects with streams of their own, so that the copy of one
-    # chunk's results overlaps the next chunk's kernels); inputs = letters in HBM, outputs = compact results
-    # (sorted 8-byte keys + CSR offsets + status) in page-locked host memory.
+    # chunk's results overlaps the next chunk's kernels); inputs = letters in HBM, outputs = packed results (5 bytes per
+    # hit: text position and score, in read order; 4-byte offsets and a status byte per read) in page-locked host memory.
     lib = ma.lib()
-    pipe = ctx.pipe(depth=args.depth, tau=w["tau"], flags=ma.SRC_TEXT | ma.SRC_DEVICE | ma.PIPE_COMPACT)
+    result_flag = ma.PIPE_PACKED if args.results == "packed" else ma.PIPE_COMPACT
+    pipe = ctx.pipe(depth=args.depth, tau=w["tau"], flags=ma.SRC_TEXT | ma.SRC_DEVICE | result_flag)
     n_reads = w["reads"]
 
     done_at = []                                # when each chunk's result came back (the spread of the steps goes into the line)
@@ -394,7 +398,9 @@ def main():
             "config": {"workload": args.workload, "description": w["desc"], "text_len": int(2 * (w["L"] + w["n_seqs"])),
                        "reads_per_gpu_per_step": n_reads, "distinct_chunks_per_gpu": len(d_chunks), "read_len": w["m"], "tau": w["tau"],
                        "timed_region": "per step one chunk: letters resident in HBM -> encode + search + locate + order + D2H of "
-                                       "compact results (8-B keys + CSR offsets + status) into page-locked host memory; "
+                                       + ("packed results (5 B per hit = text position + score, in read order; 4-B offset + status byte per read)"
+                                          if args.results == "packed" else "compact results (8-B keys + CSR offsets + status)") +
+                                       " into page-locked host memory; "
                                        "chunks pipelined over %d batch objects (gpumap_pipe)" % args.depth,
                        "parallelism": "reads sharded over %d GPU(s), index replicated (RCCL broadcast)" % world},
             "located_per_step": located_total / args.steps,
@@ -468,7 +474,7 @@ def gather_ceiling(footprint_bytes):
 
 def pcie_inclusive(ma, ctx, codes, offs, w, depth):
     """The boundary hands over host buffers: figures for DESIGN.md, never `value`.  (a) pipelined: chunks of letters
-    in page-locked host memory through gpumap_pipe (H2D + encode + search + locate + order + D2H of compact results,
+    in page-locked host memory through gpumap_pipe (H2D + encode + search + locate + order + D2H of packed results,
     the stages of consecutive chunks overlapping); (b) one shot: gpumap_map_batch, codes in, the full structure of
     arrays out, pageable (malloc'ed results, any caller) and page-locked (gpumap_host_alloc + option pinned_results)."""
     import ctypes as C
@@ -483,7 +489,7 @@ def pcie_inclusive(ma, ctx, codes, offs, w, depth):
         v = np.ctypeslib.as_array(C.cast(pin, C.POINTER(C.c_uint8)), shape=(flat.nbytes,))
         v[:] = lut[np.roll(flat, 1000 * k * w["m"])]                   # (the same reads in another order)
         pins.append((pin, v))
-    pipe = ctx.pipe(depth=depth, tau=w["tau"], flags=ma.SRC_TEXT | ma.PIPE_COMPACT)
+    pipe = ctx.pipe(depth=depth, tau=w["tau"], flags=ma.SRC_TEXT | ma.PIPE_PACKED)
     off_arr = np.ascontiguousarray(offs, dtype=np.int64)
 
     def go(k_steps):

@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GPUMAP_LIB") or os.path.join(_HERE, "lib", "libgpumap.so")      # (GPUMAP_LIB: A/B runs of two builds)
 QUERY_PREFIX, QUERY_SUFFIX = 0, 1
 SRC_TEXT, SRC_DEVICE, PIPE_COMPACT = 1, 2, 4
+PIPE_PACKED = 32
 MAX_TAU = 7
 MAX_READ_LEN = 256
 NOALLOC_MAX_QUERIES = 16384
@@ -57,6 +58,7 @@ class _Hits(C.Structure):
         ("ms_total", C.c_float), ("arena", C.c_void_p),
         ("loc_key", C.POINTER(C.c_uint64)), ("key_pos_bits", C.c_int32), ("expanded", C.c_int32),
         ("line_text", C.c_void_p), ("line_bytes", C.c_int64),
+        ("loc_packed", C.POINTER(C.c_uint8)), ("read_first32", C.POINTER(C.c_uint32)), ("status8", C.POINTER(C.c_uint8)),
     ]
 
 
@@ -225,10 +227,19 @@ class Hits:
             return np.ctypeslib.as_array(p, shape=(max(n, 1),))[:n].astype(dt, copy=True) if n > 0 else np.zeros(0, dt)
         R, L, H = raw.n_reads, raw.n_locs, raw.n_hits
         self.n_reads, self.n_locs, self.n_hits, self.n_ext = R, L, H, raw.n_ext
-        self.status = arr(raw.status, R, np.int64)
-        self.read_first_loc = arr(raw.read_first_loc, R + 1, np.int64)
         self.key_pos_bits = raw.key_pos_bits
-        self.loc_key = arr(raw.loc_key, L, np.uint64) if raw.loc_key else None
+        if raw.loc_packed and not raw.loc_key:
+            # packed result (GPUMAP_PIPE_PACKED): 5 bytes per hit, 4-byte offsets, a status byte per read
+            self.status = -arr(raw.status8, R, np.int64)
+            self.read_first_loc = arr(raw.read_first32, R + 1, np.int64)
+            p = arr(raw.loc_packed, 5 * L, np.uint64).reshape(-1, 5)
+            low = p[:, 0] | (p[:, 1] << np.uint64(8)) | (p[:, 2] << np.uint64(16)) | (p[:, 3] << np.uint64(24)) | (p[:, 4] << np.uint64(32))
+            reads = np.repeat(np.arange(R, dtype=np.uint64), np.diff(self.read_first_loc))
+            self.loc_key = (reads << np.uint64(raw.key_pos_bits + 4)) | low
+        else:
+            self.status = arr(raw.status, R, np.int64)
+            self.read_first_loc = arr(raw.read_first_loc, R + 1, np.int64)
+            self.loc_key = arr(raw.loc_key, L, np.uint64) if raw.loc_key else None
         if raw.loc_read:
             for k in ("loc_read", "loc_pos", "loc_fwd", "loc_seq", "loc_seqpos"):
                 setattr(self, k, arr(getattr(raw, k), L, np.int64))

@@ -65,6 +65,8 @@ struct gpumap_batch {
    int lines_per_rec = 0;
    int64_t first_line = 1, line_bytes = 0;
    bool have_lines = false;
+   DevBuf packed, first32, status8;  // k_pack_results: the packed result
+   bool have_packed = false;
    DevBuf seg_first;                 // k_seg_first: where the segments of the sort by segments begin
    DevBuf big_start, big_cnt;        // k_order_first: the runs of keys it left to k_order_big
    DevBuf sc_flags, sc_alias;        // gpumap_ann_build with the reference's reuse of searches (sc_plan)
@@ -1636,6 +1638,19 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
          }
          HIP_TRY(hipGetLastError());
       }
+      b->have_packed = false;
+      if ((result_flags & GM_RESULT_PACKED) && compact && !(result_flags & GM_RESULT_LINES)) {
+         // the packed result: what the link carries, made from the sorted keys, the offsets and the status
+         HIP_TRY(b->packed.ensure(20 * (size_t)cdiv(std::max<int64_t>(L, 1), 4) + 16));
+         HIP_TRY(b->first32.ensure(4 * (size_t)(R + 1)));
+         HIP_TRY(b->status8.ensure((size_t)std::max<int64_t>(R, 1)));
+         const int64_t threads = std::max<int64_t>(cdiv(L, 4), R + 1);
+         hipLaunchKernelGGL(k_pack_results, dim3((unsigned)cdiv(threads, 256)), dim3(256), 0, st, b->sorted_keys, L, pos_bits + 4,
+                            b->read_first.as<const int64_t>(), b->status.as<const int64_t>(), R, b->packed.as<uint32_t>(),
+                            b->first32.as<uint32_t>(), b->status8.as<uint8_t>());
+         HIP_TRY(hipGetLastError());
+         b->have_packed = true;
+      }
       if (want_intervals && H > 0) {
          GM_FAIL_IF(RS >= ((int64_t)1 << 24) - 1, "interval output supports fewer than 2^24 - 1 reads per batch.");
          GM_FAIL_IF(H >= ((int64_t)1 << 31), "too many interval hits in one batch.");
@@ -1755,11 +1770,13 @@ extern "C" void gpumap_hits_free(gpumap_hits *h)
 {
    if (!h) return;
    if (!h->arena) {
+      free(h->loc_packed); free(h->read_first32); free(h->status8);
       free(h->status); free(h->read_first_loc); free(h->loc_read); free(h->loc_pos); free(h->loc_fwd); free(h->loc_seq);
       free(h->loc_seqpos); free(h->loc_strand); free(h->loc_score); free(h->loc_key);
       free(h->hit_read); free(h->hit_fp); free(h->hit_rp); free(h->hit_sz); free(h->hit_dp); free(h->hit_score); free(h->hit_align);
    } else if (h->expanded) {          // gpumap_hits_expand malloc'ed these beside an arena-backed result
-      free(h->loc_read); free(h->loc_pos); free(h->loc_fwd); free(h->loc_seq); free(h->loc_seqpos); free(h->loc_strand); free(h->loc_score);
+      if (h->expanded & 1) { free(h->loc_read); free(h->loc_pos); free(h->loc_fwd); free(h->loc_seq); free(h->loc_seqpos); free(h->loc_strand); free(h->loc_score); }
+      if (h->expanded & 2) { free(h->status); free(h->read_first_loc); free(h->loc_key); }
    }
    memset(h, 0, sizeof *h);
 }
@@ -1805,6 +1822,7 @@ int gm_batch_fetch(gpumap_ctx *ctx, gpumap_batch *b, gpumap_hits *out, int resul
       if (result_flags & GM_RESULT_PINNED) {
          size_t need = 16 * 256 + 8 * (size_t)(2 * R + 1) + (compact ? 8 : 42) * (size_t)L + 80 * (size_t)H;
          if (result_flags & GM_RESULT_LINES) need = 1024 + (size_t)b->line_bytes;
+         else if (result_flags & GM_RESULT_PACKED) need = 16 * 256 + 5 * (size_t)R + 5 * (size_t)L + 64;
          // two arenas in turn: what a fetch hands out stays valid until the fetch after the next one on this batch
          // (the pipeline releases a slot's result before the slot is used again: one arena there)
          const int k = (result_flags & GM_RESULT_ONE_ARENA) ? 0 : b->pin_turn;
@@ -1830,6 +1848,15 @@ int gm_batch_fetch(gpumap_ctx *ctx, gpumap_batch *b, gpumap_hits *out, int resul
          GM_FAIL_IF(!(result_flags & GM_RESULT_PINNED), "hit lines come in a page-locked arena.");
          out->line_bytes = b->line_bytes;
          rc |= fetch_array(d, &out->line_text, b->lines.p, b->line_bytes, st);
+         GM_SYNC(b, st);
+         GM_FAIL_IF(rc != 0, "memory error.");
+         return 0;
+      }
+      if (result_flags & GM_RESULT_PACKED) {
+         GM_FAIL_IF(!b->have_packed, "the batch was not run for packed results.");
+         rc |= fetch_array(d, &out->status8, b->status8.p, R, st);
+         rc |= fetch_array(d, &out->read_first32, b->first32.p, R + 1, st);
+         rc |= fetch_array(d, &out->loc_packed, b->packed.p, 5 * L, st);
          GM_SYNC(b, st);
          GM_FAIL_IF(rc != 0, "memory error.");
          return 0;
@@ -1878,6 +1905,26 @@ failure_return:
 extern "C" int gpumap_hits_expand(const gpumap_ctx *ctx, gpumap_hits *h)
 {
    GM_FAIL_IF(ctx == nullptr || h == nullptr, "NULL argument.");
+   if (h->loc_packed != nullptr && h->loc_key == nullptr) {
+      // a packed result: status, offsets and keys first (the read of a hit is the one whose offsets hold it)
+      const int64_t L = h->n_locs, R = h->n_reads;
+      const int bits = h->key_pos_bits;
+      h->status = (int64_t *)malloc(8 * (size_t)std::max<int64_t>(R, 1));
+      h->read_first_loc = (int64_t *)malloc(8 * (size_t)(R + 1));
+      h->loc_key = (uint64_t *)malloc(8 * (size_t)std::max<int64_t>(L, 1));
+      if (h->arena) h->expanded |= 2;
+      GM_FAIL_IF(!h->status || !h->read_first_loc || !h->loc_key, "memory error.");
+      const int T = gm_host_threads();
+      gm_parallel_for(T, [&](int t) {
+         for (int64_t r = R * t / T; r < R * (t + 1) / T; r++) {
+            h->status[r] = h->status8[r] ? -1 : 0;
+            h->read_first_loc[r] = (int64_t)h->read_first32[r];
+            for (int64_t i = h->read_first32[r]; i < (int64_t)h->read_first32[r + 1]; i++)
+               h->loc_key[i] = ((uint64_t)r << (bits + 4)) | GPUMAP_PACKED_AT(h->loc_packed, i);
+         }
+      });
+      h->read_first_loc[R] = (int64_t)h->read_first32[R];
+   }
    if (h->loc_key == nullptr || h->loc_read != nullptr) return 0;       // nothing to do
    {
       const int64_t L = h->n_locs, n = ctx->ix.n;
@@ -1886,7 +1933,7 @@ extern "C" int gpumap_hits_expand(const gpumap_ctx *ctx, gpumap_hits *h)
       h->loc_read = (int64_t *)malloc(8 * cnt); h->loc_pos = (int64_t *)malloc(8 * cnt); h->loc_fwd = (int64_t *)malloc(8 * cnt);
       h->loc_seq = (int64_t *)malloc(8 * cnt); h->loc_seqpos = (int64_t *)malloc(8 * cnt);
       h->loc_strand = (uint8_t *)malloc(cnt); h->loc_score = (uint8_t *)malloc(cnt);
-      h->expanded = 1;
+      h->expanded |= 1;
       GM_FAIL_IF(!h->loc_read || !h->loc_pos || !h->loc_fwd || !h->loc_seq || !h->loc_seqpos || !h->loc_strand || !h->loc_score, "memory error.");
       const std::vector<int64_t> &beg = ctx->seq_beg_host;
       const int T = gm_host_threads();

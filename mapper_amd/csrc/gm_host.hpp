@@ -98,6 +98,7 @@ int gm_host_threads();     // worker threads of the host stages: GPUMAP_HOST_THR
 // derive the flags from the context's options, the pipeline brings its own.
 constexpr int GM_RESULT_PINNED = 1, GM_RESULT_COMPACT = 2, GM_RESULT_ONE_ARENA = 4, GM_RUN_SC = 8,
               GM_RUN_NO_LOCATE = 16;      // gm_batch_run: interval hits only (gpumap_ann_build), no located hits
+constexpr int GM_RESULT_PACKED = 64;      // with GM_RESULT_COMPACT: 5 bytes per hit, 4-byte offsets, a status byte per read (k_pack_results)
 constexpr int GM_RESULT_LINES = 32;       // gm_batch_run / gm_batch_fetch: the located hits as the lines mapper() prints (a batch filled with GM_SRC_FILE)
 constexpr int GM_SRC_TEXT = GPUMAP_SRC_TEXT, GM_SRC_DEVICE = GPUMAP_SRC_DEVICE, GM_SRC_FILE = GPUMAP_SRC_FILE;
 int gm_batch_fill(gpumap_ctx *ctx, gpumap_batch *b, const void *src, const int64_t *offsets, int64_t n_reads, int src_flags, bool encode_now);

@@ -1601,6 +1601,28 @@ __global__ void __launch_bounds__(256) k_order_segments(unsigned long long *keys
    for (int i = tid; i < len; i += 256) keys[b + i] = s_keys[i];
 }
 
+// Packed results: of every key the 40 bits below the read's (text position << 4 | score), four keys = five words per
+// thread; the offsets as 32-bit numbers and the status as a byte.
+__global__ void __launch_bounds__(256) k_pack_results(const unsigned long long *keys, int64_t n_locs, int low_bits, const int64_t *read_first,
+                                                      const int64_t *status, int64_t n_reads, uint32_t *packed, uint32_t *first32, uint8_t *status8)
+{
+   const int64_t t = blockIdx.x * (int64_t)256 + threadIdx.x;
+   if (4 * t < n_locs) {
+      const unsigned long long m = (1ull << low_bits) - 1ull;
+      unsigned long long v[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) v[j] = 4 * t + j < n_locs ? keys[4 * t + j] & m : 0ull;
+      uint32_t *o = packed + 5 * t;
+      o[0] = (uint32_t)v[0];
+      o[1] = (uint32_t)(v[0] >> 32) | (uint32_t)(v[1] << 8);
+      o[2] = (uint32_t)(v[1] >> 24) | (uint32_t)(v[2] << 16);
+      o[3] = (uint32_t)(v[2] >> 16) | (uint32_t)(v[3] << 24);
+      o[4] = (uint32_t)(v[3] >> 8);
+   }
+   if (t <= n_reads) first32[t] = (uint32_t)read_first[t];
+   if (t < n_reads) status8[t] = status[t] != 0 ? 1 : 0;
+}
+
 // Keeps one wavefront busy for `cycles` of the shader clock (gm_ctx_pipe_streams: do two streams run side by side?).
 __global__ void k_spin(long long cycles)
 {

@@ -134,7 +134,8 @@ extern "C" gpumap_pipe *gpumap_pipe_create(gpumap_ctx *const *ctxs, int n_ctx, i
    for (int i = 0; i < n_ctx; i++) GM_FAIL_IF(ctxs[i] == nullptr, "a context is NULL.");
    GM_FAIL_IF(depth < 1 || depth > 16, "depth out of range (1..16).");
    GM_FAIL_IF(tau < 0 || tau > GPUMAP_MAX_TAU, "argument 'tau' out of range.");
-   GM_FAIL_IF(flags & ~(GPUMAP_SRC_TEXT | GPUMAP_SRC_DEVICE | GPUMAP_SRC_FILE | GPUMAP_PIPE_COMPACT | GPUMAP_PIPE_LINES), "unknown flag.");
+   GM_FAIL_IF(flags & ~(GPUMAP_SRC_TEXT | GPUMAP_SRC_DEVICE | GPUMAP_SRC_FILE | GPUMAP_PIPE_COMPACT | GPUMAP_PIPE_LINES | GPUMAP_PIPE_PACKED), "unknown flag.");
+   GM_FAIL_IF((flags & GPUMAP_PIPE_PACKED) && (flags & GPUMAP_PIPE_LINES), "packed results or hit lines, not both.");
    GM_FAIL_IF((flags & GPUMAP_SRC_DEVICE) && n_ctx > 1, "device-resident chunks belong to one GPU: one context.");
    GM_FAIL_IF((flags & GPUMAP_SRC_FILE) && (flags & GPUMAP_SRC_DEVICE), "blocks of a read file come from host memory.");
    GM_FAIL_IF((flags & GPUMAP_PIPE_LINES) && !(flags & GPUMAP_SRC_FILE), "hit lines need the blocks of the read file (GPUMAP_SRC_FILE: the tags).");
@@ -142,7 +143,8 @@ extern "C" gpumap_pipe *gpumap_pipe_create(gpumap_ctx *const *ctxs, int n_ctx, i
    p->tau = tau;
    p->src_flags = flags & (GPUMAP_SRC_TEXT | GPUMAP_SRC_DEVICE | GPUMAP_SRC_FILE);
    p->result_flags = GM_RESULT_PINNED | GM_RESULT_ONE_ARENA |
-                     ((flags & GPUMAP_PIPE_LINES) ? GM_RESULT_LINES : ((flags & GPUMAP_PIPE_COMPACT) ? GM_RESULT_COMPACT : 0));
+                     ((flags & GPUMAP_PIPE_LINES) ? GM_RESULT_LINES : (flags & GPUMAP_PIPE_PACKED) ? (GM_RESULT_COMPACT | GM_RESULT_PACKED)
+                                                                     : (flags & GPUMAP_PIPE_COMPACT) ? GM_RESULT_COMPACT : 0);
    p->slots = std::vector<Slot>((size_t)depth * (size_t)n_ctx);
    p->ctx_submitted.assign((size_t)n_ctx, 0);
    p->ctx_turn.assign((size_t)n_ctx, 0);
@@ -268,7 +270,7 @@ extern "C" void gpumap_pipe_release(gpumap_pipe *p, gpumap_hits *hits)
       std::lock_guard<std::mutex> l(p->m);
       p->consumer_seen = true; p->consumer_tid = std::this_thread::get_id();
       for (auto &s : p->slots)
-         if (s.state == SLOT_RETURNED && s.hits.arena == hits->arena && s.hits.status == hits->status) { s.state = SLOT_FREE; break; }
+         if (s.state == SLOT_RETURNED && s.hits.arena == hits->arena) { s.state = SLOT_FREE; break; }      // (a slot's arena is its own)
    }
    const bool expanded = hits->expanded != 0;
    if (expanded) gpumap_hits_free(hits);            // (frees what gpumap_hits_expand added; the arena is the pipe's)

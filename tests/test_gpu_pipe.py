@@ -131,7 +131,8 @@ def test_device_resident_chunks(rep):
     p.close()
 
 
-@pytest.mark.parametrize("depth,flags", [(1, 0), (2, ma.PIPE_COMPACT), (3, ma.SRC_TEXT | ma.PIPE_COMPACT), (4, ma.SRC_TEXT)])
+@pytest.mark.parametrize("depth,flags", [(1, 0), (2, ma.PIPE_COMPACT), (3, ma.SRC_TEXT | ma.PIPE_COMPACT), (4, ma.SRC_TEXT),
+                                         (2, ma.PIPE_PACKED), (3, ma.SRC_TEXT | ma.PIPE_PACKED)])
 def test_pipe_returns_chunks_in_order(rep, depth, flags):
     base, seqs, ctx = rep
     codes, offs = _ragged_reads(seqs, 6000, 4 + depth)
@@ -156,6 +157,32 @@ def test_pipe_returns_chunks_in_order(rep, depth, flags):
         assert np.array_equal(h.read_first_loc, w.read_first_loc)
         assert np.array_equal(h.status, w.status)
         assert h.n_ext == w.n_ext
+    p.close()
+
+
+def test_packed_results_expand_to_the_full_structure(rep):
+    """GPUMAP_PIPE_PACKED: 5 bytes per hit, 4-byte offsets and a status byte per read cross the link; gpumap_hits_expand
+    makes status, offsets, keys and the structure of arrays from them (what a C caller does), equal to a full result;
+    releasing the result frees what the expansion allocated and the slot (the pipe goes on)."""
+    import ctypes as C
+    base, seqs, ctx = rep
+    codes, offs = _ragged_reads(seqs, 3000, 11)
+    want = ctx.map_batch(codes, offs, 2)
+    p = ctx.pipe(depth=2, tau=2, flags=ma.PIPE_PACKED)
+    for rep_ in range(5):                                     # more chunks than slots: every release must free its slot
+        p.submit(codes, offs)
+        raw, _ = p.next_raw()
+        assert raw.loc_packed and raw.read_first32 and raw.status8 and not raw.loc_key and not raw.status
+        assert ma.lib().gpumap_hits_expand(ctx._h, C.byref(raw)) == 0
+        assert raw.loc_key and raw.loc_read and raw.status and raw.expanded == 3
+        h = ma.Hits(raw)
+        p.release_raw(raw)
+        assert np.array_equal(h.located(), want.located())
+        assert np.array_equal(h.read_first_loc, want.read_first_loc)
+        assert np.array_equal(h.status, want.status)
+        for k in ("loc_fwd", "loc_seq", "loc_seqpos", "loc_strand"):
+            assert np.array_equal(getattr(h, k), getattr(want, k)), k
+    assert p.next() is None
     p.close()
 
 
