@@ -1514,6 +1514,7 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
       // ---- order: reads in input order, text positions ascending inside a read
       if (L == 0) HIP_TRY(hipMemsetAsync(b->read_first.p, 0, 8 * (size_t)(R + 1), st));
       b->have_lines = false; b->line_bytes = 0;
+      bool packed_by_order = false;      // the ordering's last kernel has written the packed hits
       if (L == 0 && (result_flags & GM_RESULT_LINES)) b->have_lines = true;
       if (L > 0) {
          hipcub::DoubleBuffer<unsigned long long> db(b->keys.as<unsigned long long>(), b->keys_alt.as<unsigned long long>());
@@ -1565,6 +1566,13 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
             // (the workgroup of a segment also orders the keys that agree from `lo` up and writes the CSR offsets of its reads)
             SegOut so;
             so.read_first = b->read_first.as<int64_t>(); so.n_reads = R; so.n_keys = L; so.read_shift = pos_bits + 4; so.seg_reads_log = read_bits - seg_bits;
+            so.packed = nullptr;
+            if ((result_flags & GM_RESULT_PACKED) && compact && !(result_flags & GM_RESULT_LINES)) {
+               // packed results: the segments' workgroups write the hits as they leave (5 bytes each) instead of the sorted keys
+               HIP_TRY(b->packed.ensure(20 * (size_t)cdiv(std::max<int64_t>(L, 1), 4) + 16));
+               so.packed = b->packed.as<uint8_t>();
+               packed_by_order = true;
+            }
             hipLaunchKernelGGL(k_order_segments<4>, dim3((unsigned)n_seg), dim3(256), 0, st, db.Current(), db.Alternate(), b->seg_first.as<const uint32_t>(),
                                lo, seg_shift, -1, false, so);
             hipLaunchKernelGGL(k_order_segments<8>, dim3((unsigned)n_seg), dim3(256), 0, st, db.Current(), db.Alternate(), b->seg_first.as<const uint32_t>(),
@@ -1644,8 +1652,9 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
          HIP_TRY(b->packed.ensure(20 * (size_t)cdiv(std::max<int64_t>(L, 1), 4) + 16));
          HIP_TRY(b->first32.ensure(4 * (size_t)(R + 1)));
          HIP_TRY(b->status8.ensure((size_t)std::max<int64_t>(R, 1)));
-         const int64_t threads = std::max<int64_t>(cdiv(L, 4), R + 1);
-         hipLaunchKernelGGL(k_pack_results, dim3((unsigned)cdiv(threads, 256)), dim3(256), 0, st, b->sorted_keys, L, pos_bits + 4,
+         const int64_t threads = packed_by_order ? R + 1 : std::max<int64_t>(cdiv(L, 4), R + 1);
+         hipLaunchKernelGGL(k_pack_results, dim3((unsigned)cdiv(threads, 256)), dim3(256), 0, st,
+                            packed_by_order ? (const unsigned long long *)nullptr : b->sorted_keys, L, pos_bits + 4,
                             b->read_first.as<const int64_t>(), b->status.as<const int64_t>(), R, b->packed.as<uint32_t>(),
                             b->first32.as<uint32_t>(), b->status8.as<uint8_t>());
          HIP_TRY(hipGetLastError());

@@ -1463,7 +1463,35 @@ struct SegOut {
    int64_t n_reads, n_keys;
    int read_shift;            // the read's bits begin here
    int seg_reads_log;         // a segment holds 2^this reads
+   uint8_t *packed;           // not nullptr: the segment's keys leave as the packed result (5 bytes each: the bits below the
+                              // read's), and the 8-byte keys are not written back
 };
+
+// The keys k[0, len) of the segment that begins at key `first_key`, as bytes [5 * first_key, 5 * (first_key + len)) of the
+// packed result: whole words by a thread each, the few bytes before the first and behind the last whole word one by one
+// (the neighbouring segments' workgroups write theirs the same way: no word is written by two of them).
+__device__ __forceinline__ void segment_write_packed(const unsigned long long *k, int len, int64_t first_key, int low_bits, uint8_t *packed, int tid)
+{
+   const unsigned long long m = (1ull << low_bits) - 1ull;
+   const int64_t g0 = 5 * first_key, g1 = g0 + 5 * (int64_t)len;
+   const int64_t w0 = (g0 + 3) >> 2, w1 = g1 >> 2;                 // whole words [w0, w1)
+   auto byte_at = [&](uint32_t l) -> uint32_t {                    // byte l of the segment's part
+      const uint32_t i = l / 5u, r = l - 5u * i;
+      return (uint32_t)((k[i] & m) >> (8u * r)) & 0xffu;
+   };
+   if (w0 < w1) {
+      uint32_t *words = reinterpret_cast<uint32_t *>(packed);
+      for (int64_t w = w0 + tid; w < w1; w += 256) {
+         const uint32_t l = (uint32_t)(4 * w - g0);
+         words[w] = byte_at(l) | (byte_at(l + 1) << 8) | (byte_at(l + 2) << 16) | (byte_at(l + 3) << 24);
+      }
+      const int head = (int)(4 * w0 - g0), tail = (int)(g1 - 4 * w1);
+      if (tid < head) packed[g0 + tid] = (uint8_t)byte_at((uint32_t)tid);
+      if (tid < tail) packed[4 * w1 + tid] = (uint8_t)byte_at((uint32_t)(4 * w1 - g0) + (uint32_t)tid);
+   } else {
+      for (int64_t g = g0 + tid; g < g1; g += 256) packed[g] = (uint8_t)byte_at((uint32_t)(g - g0));
+   }
+}
 
 __device__ __forceinline__ void segment_finish(unsigned long long *k /* LDS or global */, int len, int64_t first_key, int64_t seg, int lo_bit,
                                                const SegOut &o, int tid)
@@ -1524,6 +1552,11 @@ __global__ void __launch_bounds__(256) k_order_segments(unsigned long long *keys
          __threadfence_block();
          __syncthreads();
          segment_finish(keys + b, (int)(e - b), b, (int64_t)blockIdx.x, lo_bit, out, tid);
+         if (out.packed) {
+            __threadfence_block();
+            __syncthreads();
+            segment_write_packed(keys + b, (int)(e - b), b, out.read_shift, out.packed, tid);
+         }
       }
       return;
    }
@@ -1531,6 +1564,7 @@ __global__ void __launch_bounds__(256) k_order_segments(unsigned long long *keys
       if (tid == 0 && len == 1) s_keys[0] = keys[b];
       __syncthreads();
       segment_finish(s_keys, len, b, (int64_t)blockIdx.x, 4, out, tid);
+      if (out.packed && len == 1) segment_write_packed(s_keys, 1, b, out.read_shift, out.packed, tid);
       return;
    }
    const int rounds = (len + 255) >> 8;                      // per wavefront; its keys are [wid * rounds * 64, (wid + 1) * rounds * 64) of the segment
@@ -1598,7 +1632,8 @@ __global__ void __launch_bounds__(256) k_order_segments(unsigned long long *keys
    }
    segment_finish(s_keys, len, b, (int64_t)blockIdx.x, lo_bit, out, tid);
    __syncthreads();
-   for (int i = tid; i < len; i += 256) keys[b + i] = s_keys[i];
+   if (out.packed) segment_write_packed(s_keys, len, b, out.read_shift, out.packed, tid);
+   else for (int i = tid; i < len; i += 256) keys[b + i] = s_keys[i];
 }
 
 // Packed results: of every key the 40 bits below the read's (text position << 4 | score), four keys = five words per
@@ -1607,7 +1642,7 @@ __global__ void __launch_bounds__(256) k_pack_results(const unsigned long long *
                                                       const int64_t *status, int64_t n_reads, uint32_t *packed, uint32_t *first32, uint8_t *status8)
 {
    const int64_t t = blockIdx.x * (int64_t)256 + threadIdx.x;
-   if (4 * t < n_locs) {
+   if (keys != nullptr && 4 * t < n_locs) {                        // (nullptr: the ordering's last kernel has written the hits)
       const unsigned long long m = (1ull << low_bits) - 1ull;
       unsigned long long v[4];
 #pragma unroll

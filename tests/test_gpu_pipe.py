@@ -186,6 +186,34 @@ def test_packed_results_expand_to_the_full_structure(rep):
     p.close()
 
 
+@pytest.mark.parametrize("n_reads", [37, 6000, 60000])
+def test_packed_results_written_by_the_segment_sort(rep, n_reads):
+    """With the ordering by segments (sort_by_read=2, the default at GRCh38 size) and packed results, the segments'
+    workgroups write the 5-byte hits themselves (segment_write_packed: whole words, single bytes at the segment's
+    ends), and the 8-byte keys never leave the device.  Forced here on batches whose segments hold from no hit to a few
+    thousand, so that every alignment of a segment's first and last byte occurs; equal to the full result."""
+    base, seqs, ctx = rep
+    codes, offs = _ragged_reads(seqs, n_reads, 17)
+    want = ctx.map_batch(codes, offs, 2)
+    ctx.set_option("sort_by_read", 2)
+    try:
+        p = ctx.pipe(depth=2, tau=2, flags=ma.PIPE_PACKED)
+        try:
+            p.submit(codes, offs)
+            for k in range(3):
+                if k < 2:
+                    p.submit(codes, offs)
+                h = p.next()
+                assert np.array_equal(h.located(), want.located())
+                assert np.array_equal(h.read_first_loc, want.read_first_loc)
+                assert np.array_equal(h.status, want.status)
+            assert p.next() is None
+        finally:
+            p.close()
+    finally:
+        ctx.set_option("sort_by_read", -1)
+
+
 def test_submit_from_one_thread_beyond_the_depth_is_an_error_not_a_hang(rep, capfd, monkeypatch):
     """mapper() is single-threaded (src/mapper.c:23-40): a caller that submits depth + 1 chunks without taking a result
     gets -1 and a message from gpumap_pipe_submit (nobody else could free a slot), and 0 from gpumap_pipe_try_submit;

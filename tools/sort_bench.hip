@@ -73,9 +73,9 @@ int main(int argc, char **argv)
             CK(hipcub::DeviceRadixSort::SortKeys(tmp, need, db, (int)n, 45, 61, 0));
             const long nb = ((R - 1) >> 8) + 1;
             hipLaunchKernelGGL(gm::k_seg_first, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (const unsigned long long *)db.Current(), (int64_t)n, 45, (int64_t)nb, seg_first);
-            hipLaunchKernelGGL((gm::k_order_segments<4>), dim3((unsigned)nb), dim3(256), 0, 0, db.Current(), db.Alternate(), (const uint32_t *)seg_first, 4, 45, -1, false, gm::SegOut{nullptr, 0, 0, 37, 8});
-            hipLaunchKernelGGL((gm::k_order_segments<16>), dim3((unsigned)nb), dim3(256), 0, 0, db.Current(), db.Alternate(), (const uint32_t *)seg_first, 4, 45, 1024, false, gm::SegOut{nullptr, 0, 0, 37, 8});
-            hipLaunchKernelGGL((gm::k_order_segments<32>), dim3((unsigned)nb), dim3(256), 0, 0, db.Current(), db.Alternate(), (const uint32_t *)seg_first, 4, 45, 4096, true, gm::SegOut{nullptr, 0, 0, 37, 8});
+            hipLaunchKernelGGL((gm::k_order_segments<4>), dim3((unsigned)nb), dim3(256), 0, 0, db.Current(), db.Alternate(), (const uint32_t *)seg_first, 4, 45, -1, false, gm::SegOut{nullptr, 0, 0, 37, 8, nullptr});
+            hipLaunchKernelGGL((gm::k_order_segments<16>), dim3((unsigned)nb), dim3(256), 0, 0, db.Current(), db.Alternate(), (const uint32_t *)seg_first, 4, 45, 1024, false, gm::SegOut{nullptr, 0, 0, 37, 8, nullptr});
+            hipLaunchKernelGGL((gm::k_order_segments<32>), dim3((unsigned)nb), dim3(256), 0, 0, db.Current(), db.Alternate(), (const uint32_t *)seg_first, 4, 45, 4096, true, gm::SegOut{nullptr, 0, 0, 37, 8, nullptr});
          } else {
             CK(hipcub::DeviceRadixSort::SortKeys(nullptr, need, db, (int)n, 45, 61, 0));
             if (need > tmp_bytes) { if (tmp) CK(hipFree(tmp)); CK(hipMalloc(&tmp, need)); tmp_bytes = need; }
