@@ -47,7 +47,7 @@ struct gpumap_batch {
    // indexed relative to offsets[0]) or the caller's own device buffers
    const uint8_t *d_src = nullptr;
    const int64_t *d_off = nullptr;
-   bool src_relative = true, src_text = false, encoded = false;
+   bool src_relative = true, src_text = false, encoded = false, have_bytes = false;
    DevBuf up_src, up_off, seen;
    uint8_t *h_small = nullptr;       // page-locked: small read-backs (lengths seen, counters) and uploads (phase tables)
    hipEvent_t ev_seen = nullptr;
@@ -838,7 +838,9 @@ static const bool gm_sync_debug = getenv("GPUMAP_SYNC_DEBUG") != nullptr;      /
 
 // Encoding of a filled batch: the lengths seen (k_read_lengths, read back by gm_batch_fill) size the read
 // matrix; letters (or codes) -> codes in fixed-stride rows (k_encode) and the rows as bit planes (k_pack_planes).
-static int batch_encode(gpumap_ctx *ctx, gpumap_batch *b)
+// want_bytes = false: only the planes are written (the byte matrix is three quarters of what the kernel writes, and the
+// mapping search reads none of it); a run that needs the bytes of a batch encoded without them encodes it again.
+static int batch_encode(gpumap_ctx *ctx, gpumap_batch *b, bool want_bytes)
 {
    hipStream_t st = b->st_run;
    const int64_t n_reads = b->n_reads;
@@ -855,19 +857,19 @@ static int batch_encode(gpumap_ctx *ctx, gpumap_batch *b)
       }
       b->stride = (int)((maxlen + 127) & ~(int64_t)127);    // the rows as bit planes come in units of 128 symbols
       b->maxlen = (int)maxlen;
-      HIP_TRY(b->reads.ensure((size_t)n_reads * b->stride * (size_t)b->extra_factor));
+      if (want_bytes) HIP_TRY(b->reads.ensure((size_t)n_reads * b->stride * (size_t)b->extra_factor));
       HIP_TRY(b->reads4.ensure((size_t)n_reads * (size_t)(12 * (b->stride / 32))));
       const int64_t groups = n_reads * (b->stride / 32);
       hipLaunchKernelGGL(k_encode, dim3((unsigned)std::min<int64_t>(cdiv(groups, 256), 1 << 22)), dim3(256), 0, st,
                          b->d_src, b->d_off, b->d_end, b->src_relative ? 1 : 0, n_reads, b->stride,
-                         b->src_text ? (const uint8_t *)ctx->d_sym_table : (const uint8_t *)nullptr, b->reads.as<uint8_t>(),
+                         b->src_text ? (const uint8_t *)ctx->d_sym_table : (const uint8_t *)nullptr, want_bytes ? b->reads.as<uint8_t>() : (uint8_t *)nullptr,
                          b->reads4.as<uint32_t>());
       HIP_TRY(hipGetLastError());
    } else {
       memset(b->length_seen, 0, sizeof b->length_seen);
       b->stride = 128; b->maxlen = 1;
    }
-   b->encoded = true;
+   b->encoded = true; b->have_bytes = want_bytes;
    return 0;
 failure_return:
    return -1;
@@ -967,7 +969,7 @@ int gm_batch_fill(gpumap_ctx *ctx, gpumap_batch *b, const void *src, const int64
       if (total > 0) HIP_TRY(hipMemcpyAsync(b->up_src.p, (const uint8_t *)src + offsets[0], (size_t)total, hipMemcpyHostToDevice, st));
       HIP_TRY(hipEventRecord(b->ev_up, st));
       if (encode_now) {
-         GM_FAIL_IF(batch_encode(ctx, b) != 0, "cannot encode the batch.");
+         GM_FAIL_IF(batch_encode(ctx, b, true) != 0, "cannot encode the batch.");
          GM_SYNC(b, b->st_run);                         // the caller's buffers are free again
       }
    }
@@ -1061,7 +1063,11 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
       b->sorted_keys = nullptr; b->compact = compact; b->n_big = 0;
       // ---- K4 (a staged batch): letters -> codes -> bit planes, inside the timed region
       HIP_TRY(hipEventRecord(b->ev[5], st));
-      if (!b->encoded) GM_FAIL_IF(batch_encode(ctx, b) != 0, "cannot encode the batch.");
+      {
+         // the byte matrix of the reads: for blocksc_trail (k_sc_prepare, the plan's queries) and the hits' alignments (k_unpack_hits)
+         const bool want_bytes = (result_flags & GM_RUN_SC) != 0 || want_intervals != 0;
+         if (!b->encoded || (want_bytes && !b->have_bytes)) GM_FAIL_IF(batch_encode(ctx, b, want_bytes) != 0, "cannot encode the batch.");
+      }
       // ---- schedule: one phase-table row per read length present (src/blocksearch.c:138-170); for blocksc_trail
       // one per (length, tau - N count, strand class) (src/blocksearch.c:55-70)
       const bool sc = (result_flags & GM_RUN_SC) != 0;
@@ -1260,7 +1266,7 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
          HIP_TRY(hipMemsetAsync(cnt, 0, CNT_BYTES, st));
          SearchArgs A;
          A.ix = ctx->ix;
-         A.reads = b->reads.as<const uint8_t>(); A.read_len = b->read_len.as<const uint16_t>();
+         A.reads = b->reads.as<const uint8_t>(); A.planes = b->reads4.as<const uint32_t>(); A.read_len = b->read_len.as<const uint16_t>();
          A.len_row = b->len_row.as<const uint16_t>(); A.phases = b->phases.as<const uint32_t>();
          A.phase_rec = b->phase_rec.as<const uint2>(); A.n_rows = std::max(rows, 1);
          A.n_reads = RS; A.stride = b->stride; A.tau = tau;

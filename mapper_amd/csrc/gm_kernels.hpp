@@ -271,9 +271,11 @@ __global__ void __launch_bounds__(256) k_encode(const uint8_t *src, const int64_
             c[j] = y;
          }
       }
-      uint4 *d = reinterpret_cast<uint4 *>(dst + r * stride + 32 * g);
-      d[0] = make_uint4(c[0], c[1], c[2], c[3]);
-      d[1] = make_uint4(c[4], c[5], c[6], c[7]);
+      if (dst != nullptr) {                 // (nullptr: nobody reads the byte matrix in this run: the mapping search and k_verify read the planes)
+         uint4 *d = reinterpret_cast<uint4 *>(dst + r * stride + 32 * g);
+         d[0] = make_uint4(c[0], c[1], c[2], c[3]);
+         d[1] = make_uint4(c[4], c[5], c[6], c[7]);
+      }
       uint32_t pl[3] = {0, 0, 0};
 #pragma unroll
       for (int j = 0; j < 8; j++)
@@ -330,7 +332,8 @@ __global__ void k_encode_flat(const uint8_t *src, int64_t n, const uint8_t *tabl
 // ------------------------------------------------------------------------------------------------
 struct SearchArgs {
    IndexDev ix;
-   const uint8_t  *reads;       // [n_reads][stride] codes
+   const uint8_t  *reads;       // [n_reads][stride] codes (the blocksc_trail search; the mapping search reads `planes`)
+   const uint32_t *planes;      // [n_reads][3 * stride / 32] the rows as bit planes (k_encode)
    const uint16_t *read_len;    // [n_reads]
    const uint16_t *len_row;     // [MAX_READ + 1] -> row of `phases`, NO_ROW = the reference returns -1
    const uint32_t *phases;      // [rows][MAX_PHASES]
@@ -635,7 +638,8 @@ __device__ __forceinline__ void verify_replay(const VerifyArgs &A, const Node &n
                   for (int p = 0; p < 3; p++) tw[p][w] |= (uint32_t)((t >> p) & 1) << (k & 31);
                }
          }
-         const int qc = A.reads[(size_t)read * A.stride + k];
+         const uint32_t *qpl = reinterpret_cast<const uint32_t *>(A.reads4) + (size_t)read * (size_t)(3 * (A.stride >> 5)) + 3 * (k >> 5);
+         const int qc = (int)(((qpl[0] >> (k & 31)) & 1u) | (((qpl[1] >> (k & 31)) & 1u) << 1) | (((qpl[2] >> (k & 31)) & 1u) << 2));
          const uint64_t bit = 1ull << (k & 63);
 #pragma unroll
          for (int c = 0; c < NCH; c++) {

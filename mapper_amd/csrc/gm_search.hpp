@@ -187,8 +187,8 @@ __global__ void __launch_bounds__(WG_THREADS) k_search(SearchArgs A)
    uint64_t mm = 0;
    uint32_t read = 0, meta = 0;
    int pos = 0;
-   uint4 qword = make_uint4(0, 0, 0, 0);   // sixteen query symbols around pos (one load per 16 letters of a walk: a load
-   int qword_at = -1;                      // per four letters was a fifth of the kernel's requests to the L2); pos >> 4 of them, -1 = none
+   uint4 qword = make_uint4(0, 0, 0, 0);   // the query symbols around pos (one load per 16 letters of a walk, SC, or per 32, the planes:
+   int qword_at = -1;                      // a load per four letters was a fifth of the kernel's requests to the L2); pos >> 4 (>> 5) of them, -1 = none
    unsigned long long ext_count = 0;
    uint32_t jump_steps = 0;     // extension steps of this lane's seeds that the jump table stood in for
 #ifdef GM_STEP_HIST
@@ -260,12 +260,31 @@ __global__ void __launch_bounds__(WG_THREADS) k_search(SearchArgs A)
                         if (A.jump != nullptr && sd.pos - sd.end >= A.jump_k) { jt = A.jump; jk = A.jump_k; }
                         else if (A.jump2 != nullptr && sd.pos - sd.end >= A.jump2_k) { jt = A.jump2; jk = A.jump2_k; }
                         if (jt != nullptr) {
-                           const uint8_t *qp = A.reads + (size_t)rd * A.stride + sd.pos;
                            uint32_t idx = 0, bad = 0;
-                           for (int t = 0; t < jk; t++) {
-                              const uint32_t sym = qp[-t];
-                              bad |= sym & ~3u;
-                              idx |= (sym & 3u) << (2 * t);
+                           if constexpr (SC) {
+                              const uint8_t *qp = A.reads + (size_t)rd * A.stride + sd.pos;
+                              for (int t = 0; t < jk; t++) {
+                                 const uint32_t sym = qp[-t];
+                                 bad |= sym & ~3u;
+                                 idx |= (sym & 3u) << (2 * t);
+                              }
+                           } else {
+                              // the jk letters that end at sd.pos out of the row's bit planes (two runs of 12 bytes hold them):
+                              // bit t of plane p, reversed, is bit p of the letter at sd.pos - t
+                              const int lo = sd.pos - jk + 1;
+                              const int wb = (sd.pos >> 5) > 0 ? (sd.pos >> 5) - 1 : 0;
+                              const uint32_t *qp = A.planes + (size_t)rd * (size_t)(3 * (A.stride >> 5)) + 3 * wb;
+                              const uint32_t sh = (uint32_t)(lo - 32 * wb), keep = (1u << jk) - 1u;     // (jk <= 16)
+                              uint32_t x[3];
+#pragma unroll
+                              for (int pl = 0; pl < 3; pl++)
+                                 x[pl] = (uint32_t)((((uint64_t)qp[3 + pl] << 32) | (uint64_t)qp[pl]) >> sh) & keep;
+                              bad = x[2];                                      // N, an unknown letter
+                              auto spread = [](uint32_t v) {                   // bit t -> bit 2t
+                                 v = (v | (v << 8)) & 0x00ff00ffu; v = (v | (v << 4)) & 0x0f0f0f0fu;
+                                 v = (v | (v << 2)) & 0x33333333u; return (v | (v << 1)) & 0x55555555u;
+                              };
+                              idx = spread(__brev(x[0]) >> (32 - jk)) | (spread(__brev(x[1]) >> (32 - jk)) << 1);
                            }
                            if (!bad) {
                               const uint4 e = jt[idx];
@@ -343,9 +362,16 @@ __global__ void __launch_bounds__(WG_THREADS) k_search(SearchArgs A)
          quad_fetch<0>(occ, b1 << 6, need1m, sub16, f10); quad_fetch<1>(occ, b1 << 6, need1m, sub16, f11);
          quad_fetch<2>(occ, b1 << 6, need1m, sub16, f12); quad_fetch<3>(occ, b1 << 6, need1m, sub16, f13);
       }
-      if (have && (pos >> 4) != qword_at) {
-         qword_at = pos >> 4;
-         qword = *reinterpret_cast<const uint4 *>(A.reads + (size_t)read * A.stride + (pos & ~15));    // (rows are multiples of 128 bytes)
+      if constexpr (SC) {
+         if (have && (pos >> 4) != qword_at) {
+            qword_at = pos >> 4;
+            qword = *reinterpret_cast<const uint4 *>(A.reads + (size_t)read * A.stride + (pos & ~15));    // (rows are multiples of 128 bytes)
+         }
+      } else if (have && (pos >> 5) != qword_at) {
+         // the mapping search reads the rows' bit planes (12 bytes per 32 letters; the byte matrix is not written for it)
+         qword_at = pos >> 5;
+         const uint32_t *qp = A.planes + (size_t)read * (size_t)(3 * (A.stride >> 5)) + 3 * (pos >> 5);
+         qword.x = qp[0]; qword.y = qp[1]; qword.z = qp[2];
       }
 
       uint32_t rel0[SYMS], rel1[SYMS];
@@ -364,8 +390,14 @@ __global__ void __launch_bounds__(WG_THREADS) k_search(SearchArgs A)
       pin(g0); pin(g1); pin(g2); pin(g3);
       lane_rank(g0, g1, g2, g3, (int)(e1 & (BLOCK_POS - 1)), rel1);
       wave_sync();
-      const uint32_t qsel = (pos & 8) ? ((pos & 4) ? qword.w : qword.z) : ((pos & 4) ? qword.y : qword.x);
-      const int qc = (int)((qsel >> (8 * (pos & 3))) & 0xff);
+      int qc;
+      if constexpr (SC) {
+         const uint32_t qsel = (pos & 8) ? ((pos & 4) ? qword.w : qword.z) : ((pos & 4) ? qword.y : qword.x);
+         qc = (int)((qsel >> (8 * (pos & 3))) & 0xff);
+      } else {
+         const uint32_t qb = (uint32_t)pos & 31u;
+         qc = (int)(((qword.x >> qb) & 1u) | (((qword.y >> qb) & 1u) << 1) | (((qword.z >> qb) & 1u) << 2));
+      }
 
       // ------------------------------------------------------------ bwt_query_all, src/index_bwt.c:262-273
       const int sb0 = (int)(e0 >> SUPER_LOG), sb1 = (int)(e1 >> SUPER_LOG);
