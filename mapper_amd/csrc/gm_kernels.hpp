@@ -555,12 +555,12 @@ __device__ __forceinline__ bool test_bit(const uint64_t (&E)[NCH], int pos)
 // the window (E, S, QN; with KEEP also the window's planes, for the comparison with the other suffixes of the entry),
 // the steps of the reference schedule the walk stands for, and the sort key of the hit it ends in (~0: none).
 template <int NCH, bool KEEP>
-__device__ __forceinline__ void verify_replay(const VerifyArgs &A, const Node &nd, int q, uint64_t (&E)[NCH], uint64_t (&S)[NCH],
+__device__ __forceinline__ void verify_replay(const VerifyArgs &A, const Node &nd, int q, int64_t sa_val /* entry fp + q of the suffix array */,
+                                              uint64_t (&E)[NCH], uint64_t (&S)[NCH],
                                               uint64_t (&QN)[NCH], uint32_t (&tw)[3][2 * NCH], bool &planes, uint32_t &steps,
                                               unsigned long long &key, int64_t &p0, uint32_t &read, int &row, int &phase0,
                                               int &pos0, int &end0, bool &fw0)
 {
-   const int64_t fp = ((int64_t)nd.w[0] | ((int64_t)(nd.w[3] & 0xff) << 32)) + q;
    int pos = (int)(nd.w[3] >> 24);
    uint32_t meta = nd.w[5] & ~(1u << META_CAND);
    read = nd.w[4];
@@ -572,7 +572,7 @@ __device__ __forceinline__ void verify_replay(const VerifyArgs &A, const Node &n
    int score = (meta >> META_SCORE) & 7, sref = (meta >> META_SREF) & 7;
    phase0 = phase; pos0 = pos; end0 = end; fw0 = fw;
    const int lo = fw ? A.phase_lo[row * MAX_PHASES + phase] : pos + 1;      // lowest query position matched so far
-   p0 = sa_entry(A.ix.sa, A.ix.sar_bits, fp) - lo;                            // text position of query position 0
+   p0 = sa_val - lo;                                                        // text position of query position 0
    const int nq = (m + 31) >> 5;                                            // 32-letter words of the query row
    // the window inside the text (the planes have 512 symbols of padding: whole loads can be made)
    bool fast = p0 >= 0 && p0 + m <= A.ix.n;
@@ -824,11 +824,27 @@ __global__ void __launch_bounds__(256) k_verify(VerifyArgs A)
    const int n_pair_lanes = PAIRS ? 2 * (int)s_n[0] : 0, total = n_pair_lanes + (int)s_n[1];
    constexpr bool KEEP_PLANES = PAIRS && NCH <= 2;      // (longer reads: the registers cost more than the loads, 4.6 -> 4.9 ms at 150 nt)
    uint32_t steps_sum = 0, windows = 0;
+   // The entry and the suffix array's entry of a lane's NEXT round are fetched before this round's window is: a round then
+   // waits for one trip to memory (the window, the next round's suffix-array entry beside it) instead of three in a row.
+   auto fetch = [&](int base_, Node &nd_, int64_t &sa_) {
+      const int idx_ = base_ + lane;
+      sa_ = 0;
+      if (idx_ < total) {
+         const bool pair_ = idx_ < n_pair_lanes;
+         const int e_ = pair_ ? s_pairs[idx_ >> 1] : s_singles[idx_ - n_pair_lanes];
+         nd_ = A.list[tile0 + e_];
+         sa_ = sa_entry(A.ix.sa, A.ix.sar_bits, ((int64_t)nd_.w[0] | ((int64_t)(nd_.w[3] & 0xff) << 32)) + (pair_ ? (idx_ & 1) : 0));
+      }
+   };
+   Node nd, nd_next;
+   int64_t sa_val, sa_next;
+   fetch((int)(threadIdx.x & ~63u), nd, sa_val);
    for (int base = (int)(threadIdx.x & ~63u); base < total; base += 256) {      // (per wave: a wave with nothing left to do leaves)
       const int idx = base + lane;
       const bool mine = idx < total;                    // this lane replays a suffix
       const bool pair = idx < n_pair_lanes;
       const int q = pair ? (idx & 1) : 0;
+      fetch(base + 256, nd_next, sa_next);
       uint32_t steps = 0;                 // this walk's steps (0 for a lane without a suffix)
       unsigned long long key = ~0ull;
       int64_t p0 = 0;
@@ -845,11 +861,7 @@ __global__ void __launch_bounds__(256) k_verify(VerifyArgs A)
 #pragma unroll
          for (int w = 0; w < 2 * NCH; w++) tw[p][w] = 0;
       bool planes = false;                // tw holds this lane's window
-      if (mine) {
-         const int e = pair ? s_pairs[idx >> 1] : s_singles[idx - n_pair_lanes];
-         Node nd = A.list[tile0 + e];
-         verify_replay<NCH, KEEP_PLANES>(A, nd, q, E, S, QN, tw, planes, steps, key, p0, read, row, phase0, pos0, end0, fw0);
-      }
+      if (mine) verify_replay<NCH, KEEP_PLANES>(A, nd, q, sa_val, E, S, QN, tw, planes, steps, key, p0, read, row, phase0, pos0, end0, fw0);
       if (PAIRS) {
          // ---- the pair: what the partner found (lanes 2k and 2k+1 of a wave; every lane takes part in the exchange)
          const uint32_t steps_o = pair_swap(steps);
@@ -886,6 +898,7 @@ __global__ void __launch_bounds__(256) k_verify(VerifyArgs A)
       const bool found = mine && key != ~0ull;
       const uint32_t s = wave_slot(found, &s_n[5], lane);
       if (found) A.stage[(size_t)blockIdx.x * A.stage_per + s] = key;
+      nd = nd_next; sa_val = sa_next;
    }
    verify_block_sums(steps_sum, windows, A.n_ext);         // (barrier inside)
    if (threadIdx.x == 0) {
@@ -950,7 +963,8 @@ __global__ void __launch_bounds__(256) k_verify_group(VerifyArgs A, const uint32
    const bool mine = valid && q < csz;
    if (mine) {
       Node nd = A.list[i];
-      verify_replay<NCH, KEEP_PLANES>(A, nd, q, E, S, QN, tw, planes, steps, key, p0, read, row, phase0, pos0, end0, fw0);
+      const int64_t sa_val = sa_entry(A.ix.sa, A.ix.sar_bits, ((int64_t)nd.w[0] | ((int64_t)(nd.w[3] & 0xff) << 32)) + q);
+      verify_replay<NCH, KEEP_PLANES>(A, nd, q, sa_val, E, S, QN, tw, planes, steps, key, p0, read, row, phase0, pos0, end0, fw0);
    }
    uint32_t best = 0;
    if (KEEP_PLANES) {
