@@ -264,11 +264,12 @@ __global__ void __launch_bounds__(256) k_encode(const uint8_t *src, const int64_
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                const uint32_t ch = (x >> (8 * q)) & 0xff;
-               uint32_t code = table ? (uint32_t)s_tab[ch] : (ch < (uint32_t)SYMS ? ch : (uint32_t)UNKNOWN);
-               if (4 * j + q >= k) code = 0xff;
+               const uint32_t code = table ? (uint32_t)s_tab[ch] : (ch < (uint32_t)SYMS ? ch : (uint32_t)UNKNOWN);
                y |= code << (8 * q);
             }
-            c[j] = y;
+            // 0xff behind the read's last letter: per word (bytes k - 4j .. 3 of it), not per letter
+            const int left = k - 4 * j;
+            c[j] = left >= 4 ? y : (left <= 0 ? 0xffffffffu : (y | (0xffffffffu << (8 * left))));
          }
       }
       if (dst != nullptr) {                 // (nullptr: nobody reads the byte matrix in this run: the mapping search and k_verify read the planes)
