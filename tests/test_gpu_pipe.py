@@ -102,6 +102,27 @@ def test_staged_batches_encode_inside_the_run(rep):
     b.close()
 
 
+def test_staged_batch_run_twice_gets_its_byte_rows_when_a_run_needs_them(rep):
+    """A staged batch is encoded inside its run, for a mapping run without the byte matrix of the reads (k_search and
+    k_verify read the bit planes).  A later run of the same batch that needs the bytes (interval output: the alignments
+    of k_unpack_hits) encodes it again, and a mapping run after that still gives the same hits."""
+    base, seqs, ctx = rep
+    codes, offs = _ragged_reads(seqs, 3000, 23)
+    want = ctx.map_batch(codes, offs, 2, want_intervals=True)
+    b = ctx.new_batch()
+    b.stage(ASCII[codes], offs, ma.SRC_TEXT)
+    b.run(2)
+    h = b.fetch()
+    assert np.array_equal(h.located(), want.located()) and h.n_ext == want.n_ext
+    b.run(2, want_intervals=True)
+    h = b.fetch()
+    assert np.array_equal(h.intervals(), want.intervals())
+    assert np.array_equal(h.located(), want.located()) and h.n_ext == want.n_ext
+    b.run(2)
+    assert np.array_equal(b.fetch().located(), want.located())
+    b.close()
+
+
 def test_device_resident_chunks(rep):
     """GPUMAP_SRC_DEVICE: letters and offsets already in HBM (the timed region of bench.py starts there)."""
     import torch
