@@ -279,8 +279,9 @@ gpumap_batch *gpumap_batch_new(gpumap_ctx *ctx);
 /* Stages the next chunk without encoding it: gpumap_batch_run then starts with the encoding (letters -> codes ->
 ** bit planes on the device), so that the run covers encode + search + locate + order.  flags: GPUMAP_SRC_TEXT =
 ** `src` holds letters (else codes 0..4); GPUMAP_SRC_DEVICE = `src` and `offsets` are device pointers that the
-** batch uses in place (no copy; they must stay valid until the run is over), else host pointers that are
-** copied to the device by the time the batch has been run. */
+** batch uses in place (no copy; they must stay valid until the last run of the staged chunk is over: a run with
+** interval output after a run without encodes the chunk again), else host pointers that are copied to the device
+** by the time the batch has been run. */
 #define GPUMAP_SRC_TEXT   1
 #define GPUMAP_SRC_DEVICE 2
 /* GPUMAP_SRC_FILE (gpumap_pipe only) = `src` holds a block of a FASTQ / FASTA / raw read file (host memory) that starts
