@@ -11,7 +11,7 @@ replica.  No collective on the data path: reads are independent units (weak scal
 batch is fixed, value = reads of all ranks / max-over-ranks time).
 
 A "step" is one pass of the hot path over one chunk of reads whose letters are resident in HBM when the
-timed region starts: encode (k_encode, k_pack_planes) + search (k_search, k_verify) +
+timed region starts: encode (k_read_lengths, k_encode) + search (k_search, k_verify) +
 suffix-array locate + ordering + the copy of the hits to page-locked host memory (packed results: per hit, in
 read order and by ascending position, 5 bytes = text position and score; per read a 4-byte offset and a status
 byte; --results compact: 8-byte keys, 8-byte offsets and status).  Steps cycle over 8 distinct chunks and go through the library's pipeline
@@ -377,10 +377,14 @@ def main():
             kern("k_stage_compact + scan + k_place + k_place_long", mean["locate"], L, "located position", 16,
                  "8-B key read from the blocks' staging slots and written to the dense array (the few hits that are intervals read "
                  "their suffix-array entries instead; not counted apart)"),
-            kern("radix sort + k_read_first", mean["order"], L, "located position", 24,
-                 "8-B key read and written once + CSR offset; the sort makes 8 passes over the keys"),
-            kern("k_encode + k_pack_planes", mean["encode"], n_reads * w["m"], "letter", 2.375,
-                 "1 B letter in, 1 B code out, 3 bits of planes"),
+            kern("ordering (radix passes + k_seg_first + k_order_segments, or the full radix sort + k_read_first)", mean["order"], L,
+                 "located position", 24,
+                 "8-B key read and written once + CSR offset; the sort by segments moves the keys 3 times (2 radix passes over the "
+                 "top 16 bits, then a workgroup orders each segment in LDS), the full sort 7 to 8 times"),
+            kern("k_read_lengths + k_encode", mean["encode"], n_reads * w["m"], "letter",
+                 1.0 + 0.375 * (128 * ((w["m"] + 127) // 128)) / w["m"],
+                 "1 B letter in, 3 bits of bit planes out per position of the read's row (rows are multiples of 128 positions); "
+                 "the byte matrix of the reads is not written in a mapping run"),
         ]
         vt = pmc_verify_traffic(args.workload)
         if vt:
