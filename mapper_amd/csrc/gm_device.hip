@@ -8,6 +8,7 @@
 #include <functional>
 #include <mutex>
 #include <string>
+#include <chrono>
 #include <vector>
 #include "gm_devctx.hpp"
 #include "gm_kernels.hpp"
@@ -1444,11 +1445,8 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
          b->n_big = n_class[0] + n_class[1];
       }
       HIP_TRY(hipEventRecord(b->ev[1], st));
-      // (the post stream has a higher priority than the run stream: it must not wait ON THE DEVICE for an event of the run
-      // stream: with chunks of a few reads that stalled both for good, as the low-priority upload stream of round 2 did;
-      // the host waits for the run stream instead, which is idle or nearly so at this point)
-      if (b->st_post != nullptr && b->st_post != st) { GM_SYNC(b, st); st = b->st_post; }
-      if (b->on_searched) { b->on_searched(); b->on_searched = nullptr; }      // (the host has waited for the search's last kernel: the run stream is free)
+      static const bool gate_timing = getenv("GPUMAP_GATE_TIMING") != nullptr;      // (debug aid: host time from the end of the search to the sort's launch)
+      const auto t_searched = std::chrono::steady_clock::now();
       b->n_hits = (int64_t)host_cnt[1];            // entries of the list, holes included
       b->n_real = (int64_t)host_cnt[7];            // hits (and candidates handed to k_verify) among them
       b->n_ext = (int64_t)host_cnt[2];
@@ -1486,6 +1484,15 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
          GM_SYNC(b, st);
          L_iv = *h_L;
       }
+      // What follows runs on the post stream.  The count above still ran on the run stream, right behind the search: the post
+      // stream is one per context and holds the ordering of the chunk before until about now; behind it the count came
+      // back 1.1 ms after the search's end, and the next chunk's k_search, which waits for this chunk's sort to be
+      // enqueued (gm_batch_set_gate), that much later.
+      // (The post stream never waits ON THE DEVICE for an event of the run stream: with priorities and chunks of a few reads
+      // that stalled both for good, as the low-priority upload stream of round 2 did.  The host waits for the run stream.)
+      if (b->st_post != nullptr && b->st_post != st) { if (n_look <= 0) GM_SYNC(b, st); st = b->st_post; }
+      if (b->on_searched) { b->on_searched(); b->on_searched = nullptr; }      // (the host has waited for the run stream's last kernel: it is free)
+      const auto t_counted = std::chrono::steady_clock::now();
       const int64_t L = n_stage1 + n_stage2[0] + n_stage2[1] + L_iv;
       b->n_locs = L;
       if (L > 0) {
@@ -1597,6 +1604,10 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
             HIP_TRY(hipcub::DeviceRadixSort::SortKeys(b->cub_tmp.p, tmp, db, (int)L, begin_bit, end_bit, st));
             b->sorted_keys = db.Current();
          }
+         if (gate_timing)
+            fprintf(stderr, "[gate] batch %p: %.0f us from the search's end to the sort's launch (%.0f us until the number of located hits was known)\n", (void *)b,
+                    std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_searched).count(),
+                    std::chrono::duration<double, std::micro>(t_counted - t_searched).count());
          if (b->on_ordering) { b->on_ordering(); b->on_ordering = nullptr; }
          if (by_read) {
             const int64_t ob = cdiv(L, 256);
