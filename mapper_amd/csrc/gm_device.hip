@@ -42,6 +42,7 @@ struct gpumap_batch {
    // per chunk; which of the two a run got was a matter of a host round trip taking 0.2 or 1 ms)
    std::function<void()> before_search, on_ordering;
    hipEvent_t ev_sync = nullptr, ev_up = nullptr;
+   hipEvent_t ev_drain = nullptr;       // on the post stream, before this run's first kernel there: what the runs before left on that stream is done
    int64_t n_reads = 0;
    int stride = 0, maxlen = 1;
    // the letters (or codes) of the reads in device memory: the library's copy of a host buffer (up_src, up_off;
@@ -104,7 +105,7 @@ struct gpumap_batch {
                         &blk_cnt2[0], &blk_cnt2[1], &blk_off2[0], &blk_off2[1]})
          b->release();
       for (auto &e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
-      for (hipEvent_t *e : {&ev_seen, &ev_sync, &ev_up}) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
+      for (hipEvent_t *e : {&ev_seen, &ev_sync, &ev_up, &ev_drain}) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
       for (int k = 0; k < 2; k++) if (pin_arena[k]) { gm_pinned_give(pin_arena[k], pin_cap[k]); pin_arena[k] = nullptr; }
       pin_cap[0] = pin_cap[1] = 0;
       if (h_small) { (void)hipHostFree(h_small); h_small = nullptr; }
@@ -725,6 +726,7 @@ extern "C" gpumap_batch *gpumap_batch_new(gpumap_ctx *ctx)
    HIP_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
    b->st_run = b->st_copy = b->st_up = b->st_post = b->stream;
    HIP_TRY(hipEventCreateWithFlags(&b->ev_sync, hipEventDisableTiming | hipEventBlockingSync));
+   HIP_TRY(hipEventCreateWithFlags(&b->ev_drain, hipEventDisableTiming | hipEventBlockingSync));
    HIP_TRY(hipEventCreateWithFlags(&b->ev_up, hipEventDisableTiming));
    HIP_TRY(hipHostMalloc((void **)&b->h_small, H_SMALL_BYTES, hipHostMallocDefault));
    HIP_TRY(hipEventCreateWithFlags(&b->ev_seen, hipEventDisableTiming));
@@ -1049,6 +1051,27 @@ struct SmallStage {
    }
 };
 
+// The suffixes of the list's intervals added up (the locate stage's slots): sizes, their scan, the total to *h_total
+// (page-locked) -- enqueued on `st`, read by the host after its next wait for that stream.
+static int batch_count_intervals(gpumap_batch *b, hipStream_t st, int64_t n_look, const uint32_t *dense, int64_t *h_total)
+{
+   HIP_TRY(b->hit_sizes.ensure(8 * (size_t)(n_look + 1)));
+   HIP_TRY(b->hit_off.ensure(8 * (size_t)(n_look + 1)));
+   HIP_TRY(hipMemsetAsync(b->hit_sizes.as<int64_t>() + n_look, 0, 8, st));
+   hipLaunchKernelGGL(k_hit_sizes, dim3((unsigned)cdiv(n_look, 256)), dim3(256), 0, st, b->hits.as<const Node>(), dense, n_look,
+                      b->hit_sizes.as<int64_t>());
+   {
+      size_t tmp = 0;
+      HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, b->hit_sizes.as<int64_t>(), b->hit_off.as<int64_t>(), (int)(n_look + 1), st));
+      HIP_TRY(b->cub_tmp.ensure(tmp));
+      HIP_TRY(hipcub::DeviceScan::ExclusiveSum(b->cub_tmp.p, tmp, b->hit_sizes.as<int64_t>(), b->hit_off.as<int64_t>(), (int)(n_look + 1), st));
+   }
+   HIP_TRY(hipMemcpyAsync(h_total, b->hit_off.as<int64_t>() + n_look, 8, hipMemcpyDeviceToHost, st));
+   return 0;
+failure_return:
+   return -1;
+}
+
 int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, int result_flags)
 {
    GM_FAIL_IF(ctx == nullptr || b == nullptr, "NULL argument.");
@@ -1307,6 +1330,8 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
       b->key_pos_bits = pos_bits;
       HIP_TRY(hipEventRecord(b->ev[4], st));
       const bool verified = use_verify != 0 && host_cnt[1] > 0;
+      int64_t *h_L = reinterpret_cast<int64_t *>(host_cnt + CNT_WORDS + CNT_SUMS);      // the suffixes of the list's intervals
+      bool iv_counted = false, iv_count_back = false;              // ... are being added up on the run stream; the host has waited for it
       int64_t n_stage1 = 0, n_stage2[2] = {0, 0}, n_iv = 0;        // keys k_verify / the two launches of k_verify_group left, entries that are intervals
       unsigned int vblocks = 0, gblocks[2] = {0, 0};
       int vstage_per = 0;
@@ -1433,10 +1458,18 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
             HIP_TRY(hipcub::DeviceScan::ExclusiveSum(b->cub_tmp.p, tmp, b->blk_cnt2[c].as<uint32_t>(), b->blk_off2[c].as<uint32_t>(), (int)ggrid.x + 1, st));
             HIP_TRY(hipMemcpyAsync(&h_tot[4 + c], b->blk_off2[c].as<uint32_t>() + ggrid.x, 4, hipMemcpyDeviceToHost, st));
          }
+         // the intervals' suffixes are counted here already where the post stream still holds the chunk before (the locate
+         // stage needs the number before it can launch anything): the count comes back with the group kernels' wait below
+         // instead of after a wait of its own behind that stream's queue (see "What follows runs on the post stream" below)
+         if (n_iv > 0 && !(result_flags & GM_RUN_NO_LOCATE) && b->st_post != nullptr && b->st_post != st && hipStreamQuery(b->st_post) == hipErrorNotReady) {
+            GM_FAIL_IF(batch_count_intervals(b, st, n_iv, b->iv_dense.as<const uint32_t>(), h_L) != 0, "cannot count the intervals' suffixes.");
+            iv_counted = true;
+         }
          if (any_group) {
             HIP_TRY(hipMemcpyAsync(host_cnt + CNT_WORDS + 64, cnt + CNT_WORDS + 64, 8 * 128, hipMemcpyDeviceToHost, st));
             GM_SYNC(b, st);
             n_stage2[0] = h_tot[4]; n_stage2[1] = h_tot[5];
+            iv_count_back = iv_counted;
          }
          for (int k = 0; k < (any_group ? CNT_SUMS : 64); k++) {
             const unsigned long long st_k = host_cnt[CNT_WORDS + k] & 0xffffffffull;
@@ -1468,30 +1501,32 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
       const uint32_t *dense = verified ? b->iv_dense.as<const uint32_t>() : (const uint32_t *)nullptr;
       int64_t L_iv = 0;
       HIP_TRY(b->read_first.ensure(8 * (size_t)(R + 1)));
-      if (n_look > 0) {
-         GM_FAIL_IF(H >= ((int64_t)1 << 31), "too many entries in the hit list (split the batch).");
-         HIP_TRY(b->hit_sizes.ensure(8 * (size_t)(n_look + 1)));
-         HIP_TRY(b->hit_off.ensure(8 * (size_t)(n_look + 1)));
-         HIP_TRY(hipMemsetAsync(b->hit_sizes.as<int64_t>() + n_look, 0, 8, st));
-         hipLaunchKernelGGL(k_hit_sizes, dim3((unsigned)cdiv(n_look, 256)), dim3(256), 0, st, b->hits.as<const Node>(), dense, n_look,
-                            b->hit_sizes.as<int64_t>());
-         size_t tmp = 0;
-         HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, b->hit_sizes.as<int64_t>(), b->hit_off.as<int64_t>(), (int)(n_look + 1), st));
-         HIP_TRY(b->cub_tmp.ensure(tmp));
-         HIP_TRY(hipcub::DeviceScan::ExclusiveSum(b->cub_tmp.p, tmp, b->hit_sizes.as<int64_t>(), b->hit_off.as<int64_t>(), (int)(n_look + 1), st));
-         int64_t *h_L = reinterpret_cast<int64_t *>(host_cnt + CNT_WORDS + CNT_SUMS);
-         HIP_TRY(hipMemcpyAsync(h_L, b->hit_off.as<int64_t>() + n_look, 8, hipMemcpyDeviceToHost, st));
+      // What follows runs on the post stream, which is one per context and may still hold the ordering of the chunk before.
+      // Behind that the count of the intervals' suffixes came back 1.1 ms after the search's end at GRCh38 size, and the next
+      // chunk's k_search, which waits for this chunk's sort to be enqueued (gm_batch_set_gate), that much later: where the
+      // post stream was busy when k_verify had ended, the count has run on the run stream (above) and is back already.
+      // Where it was idle the count runs there, beside the next chunk's encoding (with millions of intervals, 150 nt and
+      // tau 4, it takes a quarter of a millisecond).
+      // (The post stream never waits ON THE DEVICE for an event of the run stream: with priorities and chunks of a few reads
+      // that stalled both for good, as the low-priority upload stream of round 2 did.  The host waits for the run stream.)
+      bool drain_marked = false;
+      if (n_look > 0) GM_FAIL_IF(H >= ((int64_t)1 << 31), "too many entries in the hit list (split the batch).");
+      if (iv_counted) {
+         if (!iv_count_back) GM_SYNC(b, st);
+         L_iv = *h_L;
+      }
+      if (b->st_post != nullptr && b->st_post != st) {
+         if (!iv_counted) GM_SYNC(b, st);
+         st = b->st_post;
+         HIP_TRY(hipEventRecord(b->ev_drain, st));
+         drain_marked = true;
+      }
+      if (b->on_searched) { b->on_searched(); b->on_searched = nullptr; }      // (the host has waited for the run stream's last kernel: it is free)
+      if (n_look > 0 && !iv_counted) {
+         GM_FAIL_IF(batch_count_intervals(b, st, n_look, dense, h_L) != 0, "cannot count the intervals' suffixes.");
          GM_SYNC(b, st);
          L_iv = *h_L;
       }
-      // What follows runs on the post stream.  The count above still ran on the run stream, right behind the search: the post
-      // stream is one per context and holds the ordering of the chunk before until about now; behind it the count came
-      // back 1.1 ms after the search's end, and the next chunk's k_search, which waits for this chunk's sort to be
-      // enqueued (gm_batch_set_gate), that much later.
-      // (The post stream never waits ON THE DEVICE for an event of the run stream: with priorities and chunks of a few reads
-      // that stalled both for good, as the low-priority upload stream of round 2 did.  The host waits for the run stream.)
-      if (b->st_post != nullptr && b->st_post != st) { if (n_look <= 0) GM_SYNC(b, st); st = b->st_post; }
-      if (b->on_searched) { b->on_searched(); b->on_searched = nullptr; }      // (the host has waited for the run stream's last kernel: it is free)
       const auto t_counted = std::chrono::steady_clock::now();
       const int64_t L = n_stage1 + n_stage2[0] + n_stage2[1] + L_iv;
       b->n_locs = L;
@@ -1608,6 +1643,11 @@ int gm_batch_run(gpumap_ctx *ctx, gpumap_batch *b, int tau, int want_intervals, 
             fprintf(stderr, "[gate] batch %p: %.0f us from the search's end to the sort's launch (%.0f us until the number of located hits was known)\n", (void *)b,
                     std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_searched).count(),
                     std::chrono::duration<double, std::micro>(t_counted - t_searched).count());
+         // Where a chunk has many hits per read (chr21 size: locate and ordering take 6 ms, more than the next chunk's search
+         // leaves room for) the next k_search also waits until the post stream has finished the chunk before this one: without
+         // that the post stream falls behind by more every step until the pipe's slots run out, and results come in bursts.
+         static const int drain_rule = getenv("GPUMAP_PIPE_DRAIN") ? atoi(getenv("GPUMAP_PIPE_DRAIN")) : -1;      // (tuning aid: 0 never, 1 always)
+         if (b->on_ordering && drain_marked && (drain_rule < 0 ? L > 6 * R : drain_rule != 0)) HIP_TRY(hipEventSynchronize(b->ev_drain));
          if (b->on_ordering) { b->on_ordering(); b->on_ordering = nullptr; }
          if (by_read) {
             const int64_t ob = cdiv(L, 256);
