@@ -72,7 +72,8 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("GPUMAP_WORKLOAD", "grch38"))
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU (0 = the workload's)")
     ap.add_argument("--chunks", type=int, default=8, help="distinct chunks of reads per GPU resident in HBM")
-    ap.add_argument("--depth", type=int, default=3, help="batch objects of the pipeline")
+    ap.add_argument("--depth", type=int, default=4, help="batch objects of the pipeline (a result comes back 2.8 steps after its chunk "
+                    "went in: with 3 there is no slack and results come in bursts, --results compact loses 2 %% to that)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive legs (profiling runs)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
